@@ -1,0 +1,175 @@
+/*
+ * nrv.h -- C ABI of the MI355X-native ViT encoder-block hot path (libnrv_hip.so).
+ *
+ * Drop-in boundary for RandallBalestriero/noise-robust-vit's ViT / SimpleViT module API.
+ * The reference has NO native/FFI layer (it is pure PyTorch): every entry
+ * point below replaces a run of ATen ops dispatched by a reference nn.Module.forward (and its
+ * autograd backward); the replaced call site is cited as <file>:<lines> relative to
+ * /root/reference/vit_pytorch_robust/.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless stated; the caller owns every buffer,
+ *     including workspaces and saved-for-backward tensors.  Nothing here allocates, frees or
+ *     synchronises.  All work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - bf16 tensors are raw uint16 storage (bfloat16 bit pattern), row-major, leading dimension
+ *     in ELEMENTS.  "stream" tensors (the residual stream) are fp32 or bf16, selected by dtype.
+ *   - Return value: 0 = ok; < 0 = argument/shape error detected on the host before any launch
+ *     (NRV_ERR_*); > 0 = hipError_t from the launch.  No exceptions cross the ABI.
+ *   - Stateless and re-entrant; no globals except read-only kernel handles.
+ *   - Built for gfx950 only (wave64, MFMA 16x16x32 bf16, buffer_load...lds, ds_read_b64_tr_b16).
+ */
+#ifndef NRV_H_
+#define NRV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRV_ABI_VERSION 1
+
+/* dtype codes */
+#define NRV_F32 0
+#define NRV_BF16 1
+
+/* error codes */
+#define NRV_OK 0
+#define NRV_ERR_NULL (-1)        /* required pointer is NULL */
+#define NRV_ERR_SHAPE (-2)       /* shape/stride not supported (see each entry) */
+#define NRV_ERR_DTYPE (-3)       /* unknown dtype code */
+#define NRV_ERR_WORKSPACE (-4)   /* workspace too small */
+#define NRV_ERR_ALIGN (-5)       /* pointer / leading dimension not 16-byte aligned */
+#define NRV_ERR_EPILOGUE (-6)    /* unknown epilogue or missing epilogue operand */
+
+/* GEMM epilogues (fused into the MFMA kernel's store phase) */
+#define NRV_EPI_NONE 0           /* C = acc                                                     */
+#define NRV_EPI_BIAS 1           /* C = acc + bias[n]                                           */
+#define NRV_EPI_BIAS_GELU 2      /* u = acc + bias[n]; aux_out = bf16(u) (optional); C = gelu_erf(u) */
+#define NRV_EPI_BIAS_RESIDUAL 3  /* C = acc + bias[n] (bias optional) + aux[m % aux_row_mod][n] */
+#define NRV_EPI_DGELU 4          /* C = acc * gelu_erf'(aux[m][n])           (aux = saved u, bf16) */
+
+int nrv_abi_version(void);
+const char* nrv_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm  (replaces nn.LayerNorm at simple_vit.py:38,54,65 / vit.py:104,115,167 and its backward)
+ *   y = (x - mean) * rstd * gamma + beta, biased variance, eps inside the sqrt.
+ *   x [rows, dim] (x_dtype fp32|bf16, contiguous), y bf16 [rows, dim], mean/rstd fp32 [rows].
+ *   dim % 8 == 0 and dim <= 4096.
+ * ---------------------------------------------------------------------------------------- */
+int nrv_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
+                      void* y_bf16, float* mean, float* rstd,
+                      int64_t rows, int dim, float eps, void* stream);
+
+/* dx = dres + LN'(dy); dgamma/dbeta = column reductions (deterministic two-pass).
+ *   dy bf16 [rows, dim]; dres optional residual-stream gradient (dres_dtype fp32|bf16) or NULL;
+ *   dx_f32 / dx_bf16: either or both may be given (the bf16 copy feeds the next MFMA GEMM);
+ *   dgamma/dbeta fp32 [dim]: written (accumulate=0) or added to (accumulate=1).
+ *   workspace: nrv_layernorm_bwd_workspace(rows, dim) bytes. */
+size_t nrv_layernorm_bwd_workspace(int64_t rows, int dim);
+int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const float* gamma,
+                      const float* mean, const float* rstd,
+                      const void* dres, int dres_dtype,
+                      float* dx_f32, void* dx_bf16,
+                      float* dgamma, float* dbeta, int accumulate,
+                      void* workspace, size_t workspace_bytes,
+                      int64_t rows, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM "NT":  C[M,N] = A[M,K] . B[N,K]^T  (+ epilogue), bf16 operands, fp32 MFMA accumulate.
+ *   Replaces nn.Linear forward (simple_vit.py:39,41,61,62,130; vit.py MLP :40-47; utils.py:115,579)
+ *   and, with B = W^T, the input-gradient matmul of its backward.
+ *   A [M,K] bf16 lda; B [N,K] bf16 ldb; C [M,N] c_dtype (fp32|bf16) ldc.
+ *   K % 8 == 0; lda, ldb % 8 == 0; ldc*sizeof(C) % 16 == 0; all base pointers 16-byte aligned.
+ *   bias fp32 [N] (may be NULL where optional).
+ *   aux: epilogue operand [*, N] of aux_dtype with ld_aux; aux_row_mod > 0 makes the aux row
+ *        index m % aux_row_mod (broadcast of a [tokens, dim] positional table over the batch,
+ *        simple_vit.py:142-143); 0 means row m.
+ *   aux_out: optional bf16 [M,N] (ldc_aux) receiving the pre-activation for NRV_EPI_BIAS_GELU.
+ *   Output row remap (class-token slot, vit.py:341-342): if out_group > 0 the result row m is
+ *   stored at row (m / out_group) * out_group_stride + (m % out_group) + out_row_offset of C
+ *   (and of aux, when aux_row_mod == 0).
+ * ---------------------------------------------------------------------------------------- */
+int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
+                     void* C, int c_dtype, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K,
+                     int epilogue, const float* bias,
+                     const void* aux, int aux_dtype, int64_t ld_aux, int64_t aux_row_mod,
+                     void* aux_out, int64_t ld_aux_out,
+                     int64_t out_group, int64_t out_group_stride, int64_t out_row_offset,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM "TN":  C[M,N] (fp32) = beta * C + sum_t A[t,M] * B[t,N]   -- the weight-gradient matmul
+ *   dW = dY^T . X of nn.Linear's backward (contraction over tokens), split over the token axis
+ *   with a deterministic slab reduction.
+ *   A [T,M] bf16 lda; B [T,N] bf16 ldb; C fp32 ldc; beta is 0 or 1.
+ *   M % 8 == 0, N % 8 == 0; a_group/a_group_stride/a_row_offset remap the rows of A exactly as
+ *   the NT output remap does (0 = identity) so that dY laid out with a class-token slot can be used.
+ *   workspace: nrv_gemm_tn_workspace(M, N, T) bytes.
+ * ---------------------------------------------------------------------------------------- */
+size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T);
+int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
+                     float* C, int64_t ldc, int64_t M, int64_t N, int64_t T, float beta,
+                     int64_t a_group, int64_t a_group_stride, int64_t a_row_offset,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Column sum (bias gradient of nn.Linear's backward): out[n] = beta*out[n] + sum_t X[t,n].
+ *   X bf16 [T,N] ld; N % 8 == 0.  workspace: nrv_colsum_workspace(T, N) bytes. */
+size_t nrv_colsum_workspace(int64_t T, int64_t N);
+int nrv_colsum_bf16(const void* X, int64_t ld, float* out, int64_t T, int64_t N, float beta,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention (replaces simple_vit.py:68-75 -- chunk/rearrange, q k^T * scale,
+ * Softmax(-1), attn v, rearrange -- and the intended SDPA of utils.py:207-232,568-577).
+ *   qkv bf16 [B, N, 3*H*dh] exactly as the QKV projection writes it (feature index =
+ *   which*(H*dh) + h*dh + d, simple_vit.py:67-68); out bf16 [B, N, H*dh] ('b h n d -> b n (h d)');
+ *   lse fp32 [B, H, N] = log(sum_j exp(scale * q.k_j)) saved for the backward.
+ *   dh == 64, 1 <= N <= 256.  The [N,N] score matrix never leaves the CU.
+ * ---------------------------------------------------------------------------------------- */
+int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
+                 int B, int N, int H, int dh, float scale, void* stream);
+
+/* Backward: dqkv bf16 [B, N, 3*H*dh] from dout bf16 [B, N, H*dh]; recomputes P from q,k and lse.
+ *   delta_ws: fp32 [B*H*N] scratch (row sums of dout*out). */
+int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse,
+                 void* dqkv_bf16, float* delta_ws,
+                 int B, int N, int H, int dh, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch unfold (replaces einops Rearrange 'b c (h p1) (w p2) -> b h w (p1 p2 c)' simple_vit.py:126-129,
+ * and the im2col implied by Conv2d(k=s=p) vit.py:237-242,323).
+ *   img [B,C,H,W] (img_dtype fp32|bf16) -> patches bf16 [B*(H/p)*(W/p), C*p*p]
+ *   layout 0: feature order (p1, p2, c)   [SimpleViT Linear weight order]
+ *   layout 1: feature order (c, p1, p2)   [Conv2d weight.reshape(D,-1) order]
+ * ---------------------------------------------------------------------------------------- */
+#define NRV_PATCH_P1P2C 0
+#define NRV_PATCH_CP1P2 1
+int nrv_patch_unfold(const void* img, int img_dtype, void* patches_bf16,
+                     int B, int C, int H, int W, int p, int layout, void* stream);
+
+/* Weight staging: w fp32 [R,C] -> w_bf16 [R,C] and (optional) wT_bf16 [C,R]; once per optimizer step. */
+int nrv_cast_transpose(const float* w, void* w_bf16, void* wT_bf16, int64_t R, int64_t C, void* stream);
+
+/* Elementwise cast fp32 -> bf16 (n % 8 == 0 not required). */
+int nrv_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+
+/* Row gather / scatter-add of the residual stream (MAE token selection, mae.py:75-76 and its backward):
+ *   fwd: out[r, :] = src[index[r], :]   (rows_out rows, dim % 4 == 0, fp32)
+ *   bwd: dsrc[index[r], :] += dout[r, :] (indices unique per call => plain stores into a zeroed dsrc) */
+int nrv_gather_rows_f32(const float* src, const int64_t* index, float* out,
+                        int64_t rows_out, int dim, void* stream);
+int nrv_scatter_rows_f32(const float* dout, const int64_t* index, float* dsrc,
+                         int64_t rows_out, int dim, void* stream);
+
+/* Hardware-assumption probes used by tests/test_hw_probe.py (MFMA lane maps, transposed LDS read,
+ * LDS-DMA layout and out-of-range zero fill).  out: fp32 scratch written by a single wave. */
+int nrv_probe(int which, const void* in, void* out, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRV_H_ */

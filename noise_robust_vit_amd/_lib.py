@@ -1,0 +1,88 @@
+"""ctypes binding of libnrv_hip.so (the C ABI declared in include/nrv.h).
+
+The library is the product: there is NO fallback.  If it cannot be loaded, or a call returns a
+non-zero code, a RuntimeError is raised -- nothing here ever routes through PyTorch eager maths or
+the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnrv_hip.so")
+
+NRV_F32, NRV_BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
+PATCH_P1P2C, PATCH_CP1P2 = 0, 1
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
+SIGNATURES = {
+    "nrv_abi_version": (c_int, []),
+    "nrv_error_string": (c_char_p, [c_int]),
+    "nrv_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int64, c_int, c_float, c_void_p]),
+    "nrv_layernorm_bwd_workspace": (c_size_t, [c_int64, c_int]),
+    "nrv_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_size_t, c_int64, c_int, c_void_p]),
+    "nrv_gemm_nt_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64,
+                                 c_int64, c_int64, c_int64, c_int, c_void_p,
+                                 c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64,
+                                 c_int64, c_int64, c_int64, c_void_p]),
+    "nrv_gemm_tn_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "nrv_gemm_tn_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                 c_int64, c_int64, c_int64, c_float, c_int64, c_int64, c_int64,
+                                 c_void_p, c_size_t, c_void_p]),
+    "nrv_colsum_workspace": (c_size_t, [c_int64, c_int64]),
+    "nrv_colsum_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
+    "nrv_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "nrv_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "nrv_patch_unfold": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "nrv_cast_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "nrv_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nrv_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "nrv_scatter_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "nrv_probe": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NrvError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libnrv_hip.so once; raise loudly if it is missing (run `python -m noise_robust_vit_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NrvError(
+                f"{LIB_PATH} not found: the HIP kernels are the product and there is no fallback path. "
+                "Build them with `python -m noise_robust_vit_amd.build` (needs hipcc, gfx950 target).")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.nrv_abi_version()
+        if got != ABI_VERSION:
+            raise NrvError(f"libnrv_hip.so ABI version {got} != binding version {ABI_VERSION}; rebuild the library")
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().nrv_error_string(code)
+        raise NrvError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")

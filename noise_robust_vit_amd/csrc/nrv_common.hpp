@@ -1,0 +1,129 @@
+// Common device/host helpers for the gfx950 (MI355X, CDNA4) kernels of libnrv_hip.so.
+// wave = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "nrv.h"
+
+#define NRV_WAVE 64
+
+typedef unsigned short bf16_t;                                    // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;       // one MFMA 16x16x32 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;       // one ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;        // one MFMA 16x16 accumulator tile / 16 B
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> f32 (round-to-nearest-even through the compiler cast: v_cvt_pk_bf16_f32, NaN stays NaN)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    f32x2_t f = {lo, hi};
+    bf16x2v_t h = __builtin_convertvector(f, bf16x2v_t);
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float a) {
+    __bf16 h = (__bf16)a;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact-erf GELU pieces.  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): one v_rcp, one v_exp.
+//   Phi(u) = 0.5 (1 + erf(u / sqrt 2));   phi(u) = exp(-u^2/2) / sqrt(2 pi)
+// gelu(u) = u Phi(u)  (nn.GELU() default, simple_vit.py:40);  gelu'(u) = Phi(u) + u phi(u)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gelu_parts(float u, float& Phi, float& phi) {
+    const float x = fabsf(u) * 0.70710678118654752f;               // |u| / sqrt(2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    // e = exp(-x^2) = exp2(-u^2/2 * log2 e)
+    const float e = __builtin_amdgcn_exp2f(u * u * -0.72134752044448170f);
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_abs = p * t * e;                              // 1 - erf(|x|)
+    const float half_erfc = 0.5f * erfc_abs;
+    Phi = (u >= 0.0f) ? (1.0f - half_erfc) : half_erfc;
+    phi = e * 0.39894228040143268f;
+}
+__device__ __forceinline__ float gelu_fwd(float u) {
+    float Phi, phi;
+    gelu_parts(u, Phi, phi);
+    return u * Phi;
+}
+__device__ __forceinline__ float gelu_grad(float u) {
+    float Phi, phi;
+    gelu_parts(u, Phi, phi);
+    return fmaf(u, phi, Phi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// buffer resources: out-of-range offsets read as zero, which is how every tile tail is handled.
+// The descriptor is built from wave-uniform values only (blockIdx / kernel arguments).
+// ---------------------------------------------------------------------------------------------
+#define NRV_OOB 0x80000000u   // a voffset that is always >= num_records (records are clamped below this)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint64_t bytes) {
+    const unsigned rec = bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)rec, 0x00020000);
+}
+
+// 16-byte LDS-DMA: lane l's 16 bytes land at lds_base + 16*l (lds_base wave-uniform).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_base), 16, voffset, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {
+    return *reinterpret_cast<const bf16x8_t*>(p);
+}
+__device__ __forceinline__ bf16x4_t lds_read_tr16_b64(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) bf16x4_t*)(p));
+}
+__device__ __forceinline__ bf16x8_t cat4(bf16x4_t a, bf16x4_t b) {
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware bijective block remap (8 XCDs, blocks are dealt round-robin): consecutive logical
+// ids end up on one XCD so that neighbouring tiles share an L2.  Speed only, never correctness.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
+    const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+#define NRV_CHECK_LAUNCH()                          \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+static inline bool nrv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t nrv_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

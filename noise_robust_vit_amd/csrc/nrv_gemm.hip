@@ -1,0 +1,482 @@
+// MFMA bf16 GEMM kernels for gfx950 (MI355X).
+//
+//   gemm_nt_kernel : C[M,N] = A[M,K] . B[N,K]^T (+ fused epilogue)      -- nn.Linear forward / dX
+//   gemm_tn_kernel : C[M,N] = sum_t A[t,M] B[t,N], split over t          -- nn.Linear dW
+//
+// Shared structure (one workgroup = one 256x256 output tile, 512 threads = 8 waves as 2(M) x 4(N),
+// each wave owns 128x64 = 8x4 MFMA 16x16x32 accumulator tiles = 128 VGPRs):
+//   * operands are staged HBM -> LDS by 16-byte LDS-DMA (buffer_load ... lds): no VGPR round trip,
+//     out-of-range rows / k-chunks read as zero through the buffer descriptor, which is the only
+//     tail handling the main loop needs;
+//   * 2 LDS stages of (32 KiB A + 32 KiB B), BK = 64: tile k+1 is in flight while tile k is
+//     multiplied; one vmcnt(0) + barrier per K-step (cdna_hip_programming.md §5, "glds, 2 LDS
+//     buffers, BK=64" row);
+//   * the LDS image is lane-linear per DMA instruction, so bank-conflict swizzles are applied to
+//     the per-lane SOURCE address and undone on the fragment read (rule 21);
+//   * accumulators are held "transposed" (MFMA(Bfrag, Afrag)): a lane owns 4 consecutive output
+//     columns of one row, the epilogue transposes 16x64 slabs through a wave-private LDS patch and
+//     every global access of the epilogue is a full 16-byte, row-contiguous access.
+//
+// Reference call sites replaced: simple_vit.py:39,41,61,62,130 ; vit.py:40-47 ; utils.py:115,579.
+#include "nrv_common.hpp"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int GEMM_THREADS = 512;
+constexpr int STAGE_BYTES = 65536;          // A tile 32 KiB + B tile 32 KiB
+constexpr int B_TILE_OFF = 32768;
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_BYTES;
+constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
+constexpr int EPI_PATCH_BYTES = 16 * EPI_ROW_F32 * 4;   // 4352 B per wave
+
+struct EpiParams {
+    void* C;
+    const float* bias;
+    const void* aux;
+    void* aux_out;
+    long long ldc, ld_aux, ld_aux_out;
+    int M, N;
+    int aux_row_mod;
+    int out_group, out_group_stride, out_row_offset;
+};
+
+struct GemmNTParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    long long lda, ldb;
+    int K;
+    int tiles_n;
+    EpiParams e;
+};
+
+struct GemmTNParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    long long lda, ldb;
+    int T;
+    int tiles_n, tiles_mn;
+    int splits, kt_per_split;     // K-tiles (of 64 token rows) per split
+    int a_group, a_group_stride, a_row_offset;
+    long long slab_stride;        // elements between split slabs (0 when splits == 1)
+    EpiParams e;
+};
+
+// rows are < 2^31 (host-checked), so the remap stays in 32-bit integer arithmetic
+__device__ __forceinline__ int remap_row(int m, int group, int group_stride, int offset) {
+    if (group <= 0) return m;
+    const int g = m / group;
+    return g * group_stride + (m - g * group) + offset;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue shared by both kernels.  acc[mi][ni] holds, for lane l: row  m = 16 mi + (l & 15),
+// columns n = 16 ni + 4 (l >> 4) + {0,1,2,3} of the wave's 128 x 64 block.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, bool OUT_F32, bool AUX_F32>
+__device__ __forceinline__ void epilogue(f32x4_t (&acc)[8][4], char* smem, const EpiParams& e,
+                                         int row_base /* global row of the wave's block */,
+                                         int col_base /* global col of the wave's block */,
+                                         int lane, int wave) {
+    float* stg = reinterpret_cast<float*>(smem + wave * EPI_PATCH_BYTES);
+    const int wc_row = lane & 15, wg = lane >> 4;       // write side: row within slab, column group
+    const int rcol4 = lane & 15, rrow = lane >> 4;      // read side: float4 column, row phase
+    const int ncol = col_base + rcol4 * 4;
+    const bool col_ok = ncol < e.N;
+
+    f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == NRV_EPI_BIAS || EPI == NRV_EPI_BIAS_GELU || EPI == NRV_EPI_BIAS_RESIDUAL) {
+        if (e.bias != nullptr && col_ok) bias4 = *reinterpret_cast<const f32x4_t*>(e.bias + ncol);
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            *reinterpret_cast<f32x4_t*>(stg + wc_row * EPI_ROW_F32 + ni * 16 + wg * 4) = acc[mi][ni];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rrow + 4 * i;
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + r * EPI_ROW_F32 + rcol4 * 4);
+            const int m = row_base + mi * 16 + r;
+            if (m < e.M && col_ok) {
+                v += bias4;
+                const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
+                if (EPI == NRV_EPI_BIAS_GELU) {
+                    if (e.aux_out != nullptr) {
+                        u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.aux_out) + orow * e.ld_aux_out + ncol) = pk;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_fwd(v[j]);
+                }
+                if (EPI == NRV_EPI_BIAS_RESIDUAL) {
+                    const long long arow = e.aux_row_mod > 0 ? (long long)(m % e.aux_row_mod) : orow;
+                    if (AUX_F32) {
+                        v += *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.aux) + arow * e.ld_aux + ncol);
+                    } else {
+                        const u32x2_t a = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + arow * e.ld_aux + ncol);
+                        v[0] += bf16lo_to_f32(a[0]); v[1] += bf16hi_to_f32(a[0]);
+                        v[2] += bf16lo_to_f32(a[1]); v[3] += bf16hi_to_f32(a[1]);
+                    }
+                }
+                if (EPI == NRV_EPI_DGELU) {
+                    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + orow * e.ld_aux + ncol);
+                    v[0] *= gelu_grad(bf16lo_to_f32(a[0])); v[1] *= gelu_grad(bf16hi_to_f32(a[0]));
+                    v[2] *= gelu_grad(bf16lo_to_f32(a[1])); v[3] *= gelu_grad(bf16hi_to_f32(a[1]));
+                }
+                if (OUT_F32) {
+                    *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.C) + orow * e.ldc + ncol) = v;
+                } else {
+                    u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.C) + orow * e.ldc + ncol) = pk;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel.  LDS tile image: [256 rows][64 k] bf16 = 128-byte rows; 16-byte chunk c of row r is
+// stored at chunk position c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for the MFMA fragment
+// pattern (lane & 15 = row, lane >> 4 = chunk).
+// ---------------------------------------------------------------------------------------------
+template <int EPI, bool OUT_F32, bool AUX_F32>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmNTParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = p.e.M, N = p.e.N, K = p.K;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
+
+    // staging: DMA instruction i of this wave fills rows 8*(8 i + wave) .. +7 of a tile
+    unsigned st_a[4], st_b[4], st_c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        st_a[i] = (unsigned)((long long)r * p.lda * 2) + c * 16;
+        st_b[i] = (unsigned)((long long)r * p.ldb * 2) + c * 16;
+        st_c[i] = c * 8;                                   // k offset of the chunk inside the K-tile
+        // rows past M / N: the byte offset is >= num_records by construction (records = rows_left*ld*2)
+        if (m0 + r >= M) st_a[i] = NRV_OOB;
+        if (n0 + r >= N) st_b[i] = NRV_OOB;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool kok = (k0 + (int)st_c[i]) < K;
+            const unsigned va = (kok && st_a[i] != NRV_OOB) ? st_a[i] + k0 * 2 : NRV_OOB;
+            const unsigned vb = (kok && st_b[i] != NRV_OOB) ? st_b[i] + k0 * 2 : NRV_OOB;
+            dma16(ra, base + (i * 8 + wave) * 1024, va);
+            dma16(rb, base + B_TILE_OFF + (i * 8 + wave) * 1024, vb);
+        }
+    };
+
+    // fragment read offsets
+    const int fr = lane & 15, fg = lane >> 4;
+    const int swz = (fg ^ ((fr >> 1) & 7)) << 4;
+    const int a_rd = (wr * 128 + fr) * 128 + swz;
+    const int b_rd = B_TILE_OFF + (wc * 64 + fr) * 128 + swz;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BK - 1) / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[8], bfr[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bfr[ni] = lds_read_b128(sa + ((b_rd ^ (ks << 6)) + ni * 2048));
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) af[mi] = lds_read_b128(sa + ((a_rd ^ (ks << 6)) + mi * 2048));
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bfr[ni], af[mi], acc[mi][ni]);
+        }
+    }
+    __syncthreads();     // every wave is done with the tile buffers: reuse them as epilogue patches
+    epilogue<EPI, OUT_F32, AUX_F32>(acc, smem, p.e, m0 + wr * 128, n0 + wc * 64, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel.  LDS tile image: [64 token rows][256 cols] bf16 = 512-byte rows; the 32-byte unit u
+// of row R is stored at unit position u ^ (R & 7): conflict-free ds_read_b64_tr_b16 (a 32-lane
+// half reads 8 rows x 32 bytes).  Both operands are read with the same transposed pattern, so the
+// k-order permutation inside a 32-deep MFMA step is the same for A and B.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / p.tiles_mn;
+    const int tile = id - split * p.tiles_mn;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = p.e.M, N = p.e.N;
+
+    const int t_begin = split * p.kt_per_split * BK;
+    int t_end = t_begin + p.kt_per_split * BK;
+    if (t_end > p.T) t_end = p.T;
+    const int nk = t_end > t_begin ? (t_end - t_begin + BK - 1) / BK : 0;
+
+    const long long arow0 = remap_row(t_begin, p.a_group, p.a_group_stride, p.a_row_offset);
+    const bf16_t* abase = p.A + arow0 * p.lda + m0;
+    const bf16_t* bbase = p.B + (long long)t_begin * p.ldb + n0;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, 0x7fffffffull);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(bbase, 0x7fffffffull);
+
+    // staging: DMA instruction i of this wave fills token rows 2*(8 i + wave), +1 of a tile
+    int st_r[4], st_col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = 2 * (i * 8 + wave) + (lane >> 5);
+        const int ch = lane & 31;
+        const int ul = (ch >> 1) ^ (R & 7);
+        st_r[i] = R;
+        st_col[i] = (ul * 2 + (ch & 1)) * 8;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t_begin + kt * BK + st_r[i];
+            const bool tok = t < t_end;
+            const long long ar = remap_row(t, p.a_group, p.a_group_stride, p.a_row_offset) - arow0;
+            const unsigned va = (tok && (m0 + st_col[i] < M)) ? (unsigned)((ar * p.lda + st_col[i]) * 2) : NRV_OOB;
+            const unsigned vb = (tok && (n0 + st_col[i] < N)) ? (unsigned)(((long long)(t - t_begin) * p.ldb + st_col[i]) * 2) : NRV_OOB;
+            dma16(ra, base + (i * 8 + wave) * 1024, va);
+            dma16(rb, base + B_TILE_OFF + (i * 8 + wave) * 1024, vb);
+        }
+    };
+
+    // transposed fragment read offsets: lane (g = l>>4, q = (l&15)>>2, pp = l&3) supplies row 4g+q (+16 r + 32 ks)
+    const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+    const int Rl = 4 * fg + fq;
+    const int x = Rl & 7;
+    const int a_tr = Rl * 512 + (x << 5) + fp * 8 + wr * 256;
+    const int b_tr = B_TILE_OFF + Rl * 512 + ((((wc & 1) << 2) ^ x) << 5) + fp * 8 + (wc >> 1) * 256;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[8], bfr[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const char* q = sa + ((b_tr ^ (ni << 5)) + ks * (32 * 512));
+                bfr[ni] = cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const char* q = sa + ((a_tr ^ (mi << 5)) + ks * (32 * 512));
+                af[mi] = cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bfr[ni], af[mi], acc[mi][ni]);
+        }
+    }
+    __syncthreads();
+    EpiParams e = p.e;
+    e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
+    epilogue<NRV_EPI_NONE, true, true>(acc, smem, e, m0 + wr * 128, n0 + wc * 64, lane, wave);
+}
+
+// C = beta * C + sum_s slab[s]
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int splits,
+                                     float* __restrict__ C, long long ldc, int M, int N, float beta) {
+    const long long n4 = N >> 2;
+    const long long total = (long long)M * n4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / n4, c = (i - m * n4) * 4;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < splits; ++k)
+            s += *reinterpret_cast<const f32x4_t*>(slabs + k * slab_stride + m * N + c);
+        float* dst = C + m * ldc + c;
+        if (beta != 0.f) s += *reinterpret_cast<const f32x4_t*>(dst) * beta;
+        *reinterpret_cast<f32x4_t*>(dst) = s;
+    }
+}
+
+template <typename KernelT>
+int set_lds(KernelT k) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+}
+
+template <int EPI, bool OUT_F32, bool AUX_F32>
+int launch_nt(const GemmNTParams& p, int grid, hipStream_t s) {
+    static int attr = set_lds(gemm_nt_kernel<EPI, OUT_F32, AUX_F32>);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OUT_F32, AUX_F32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, p);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
+int tn_splits(int64_t M, int64_t N, int64_t T) {
+    const int64_t tiles = nrv_cdiv(M, BM) * nrv_cdiv(N, BN);
+    const int64_t kt = nrv_cdiv(T, BK);
+    int64_t s = 256 / tiles;
+    if (s < 1) s = 1;
+    if (s > kt) s = kt;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
+                                void* C, int c_dtype, int64_t ldc,
+                                int64_t M, int64_t N, int64_t K,
+                                int epilogue_id, const float* bias,
+                                const void* aux, int aux_dtype, int64_t ld_aux, int64_t aux_row_mod,
+                                void* aux_out, int64_t ld_aux_out,
+                                int64_t out_group, int64_t out_group_stride, int64_t out_row_offset,
+                                void* stream) {
+    if (!A || !B || !C) return NRV_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return NRV_ERR_SHAPE;
+    if (M > 0x7fffff00ll || N > 0x7fffff00ll || K > 0x7fffff00ll) return NRV_ERR_SHAPE;
+    if ((K & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return NRV_ERR_SHAPE;
+    if (c_dtype != NRV_F32 && c_dtype != NRV_BF16) return NRV_ERR_DTYPE;
+    const int64_t csz = c_dtype == NRV_F32 ? 4 : 2;
+    if (!nrv_aligned16(A) || !nrv_aligned16(B) || !nrv_aligned16(C) || ((ldc * csz) & 15)) return NRV_ERR_ALIGN;
+    if (lda * 2 * 256 >= 0x7fffffffll || ldb * 2 * 256 >= 0x7fffffffll) return NRV_ERR_SHAPE;
+    if (out_group < 0 || (out_group > 0 && out_group_stride < out_group)) return NRV_ERR_SHAPE;
+    const bool need_aux = epilogue_id == NRV_EPI_BIAS_RESIDUAL || epilogue_id == NRV_EPI_DGELU;
+    if (need_aux) {
+        if (!aux) return NRV_ERR_EPILOGUE;
+        if (aux_dtype != NRV_F32 && aux_dtype != NRV_BF16) return NRV_ERR_DTYPE;
+        if (epilogue_id == NRV_EPI_DGELU && aux_dtype != NRV_BF16) return NRV_ERR_DTYPE;
+        const int64_t asz = aux_dtype == NRV_F32 ? 4 : 2;
+        if (ld_aux < N || ((ld_aux * asz) & 15) || !nrv_aligned16(aux)) return NRV_ERR_ALIGN;
+    }
+    if ((epilogue_id == NRV_EPI_BIAS || epilogue_id == NRV_EPI_BIAS_GELU) && !bias) return NRV_ERR_EPILOGUE;
+    if (bias && !nrv_aligned16(bias)) return NRV_ERR_ALIGN;
+    if (aux_out && (ld_aux_out < N || (ld_aux_out & 7) || !nrv_aligned16(aux_out))) return NRV_ERR_ALIGN;
+
+    GemmNTParams p;
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.lda = lda; p.ldb = ldb; p.K = (int)K;
+    const int tiles_m = (int)nrv_cdiv(M, BM), tiles_n = (int)nrv_cdiv(N, BN);
+    p.tiles_n = tiles_n;
+    p.e.C = C; p.e.bias = bias; p.e.aux = aux; p.e.aux_out = aux_out;
+    p.e.ldc = ldc; p.e.ld_aux = ld_aux; p.e.ld_aux_out = ld_aux_out;
+    p.e.M = (int)M; p.e.N = (int)N;
+    p.e.aux_row_mod = (int)aux_row_mod;
+    p.e.out_group = (int)out_group; p.e.out_group_stride = (int)out_group_stride; p.e.out_row_offset = (int)out_row_offset;
+    const int grid = tiles_m * tiles_n;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool of32 = c_dtype == NRV_F32;
+    const bool af32 = aux_dtype == NRV_F32;
+    switch (epilogue_id) {
+        case NRV_EPI_NONE:
+            return of32 ? launch_nt<NRV_EPI_NONE, true, true>(p, grid, s) : launch_nt<NRV_EPI_NONE, false, true>(p, grid, s);
+        case NRV_EPI_BIAS:
+            return of32 ? launch_nt<NRV_EPI_BIAS, true, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS, false, true>(p, grid, s);
+        case NRV_EPI_BIAS_GELU:
+            return of32 ? launch_nt<NRV_EPI_BIAS_GELU, true, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS_GELU, false, true>(p, grid, s);
+        case NRV_EPI_BIAS_RESIDUAL:
+            if (of32) return af32 ? launch_nt<NRV_EPI_BIAS_RESIDUAL, true, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS_RESIDUAL, true, false>(p, grid, s);
+            return af32 ? launch_nt<NRV_EPI_BIAS_RESIDUAL, false, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS_RESIDUAL, false, false>(p, grid, s);
+        case NRV_EPI_DGELU:
+            return of32 ? launch_nt<NRV_EPI_DGELU, true, false>(p, grid, s) : launch_nt<NRV_EPI_DGELU, false, false>(p, grid, s);
+        default:
+            return NRV_ERR_EPILOGUE;
+    }
+}
+
+extern "C" size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T) {
+    if (M <= 0 || N <= 0 || T <= 0) return 0;
+    const int s = tn_splits(M, N, T);
+    return (size_t)s * (size_t)M * (size_t)N * 4;   // covers the beta == 1 case of a single split too
+}
+
+extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
+                                float* C, int64_t ldc, int64_t M, int64_t N, int64_t T, float beta,
+                                int64_t a_group, int64_t a_group_stride, int64_t a_row_offset,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !B || !C) return NRV_ERR_NULL;
+    if (M <= 0 || N <= 0 || T <= 0) return NRV_ERR_SHAPE;
+    if (M > 0x7fffff00ll || N > 0x7fffff00ll || T > 0x7fffff00ll) return NRV_ERR_SHAPE;
+    if ((M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < M || ldb < N || ldc < N || (ldc & 3)) return NRV_ERR_SHAPE;
+    if (!nrv_aligned16(A) || !nrv_aligned16(B) || !nrv_aligned16(C)) return NRV_ERR_ALIGN;
+    if (beta != 0.f && beta != 1.f) return NRV_ERR_SHAPE;
+    if (a_group < 0 || (a_group > 0 && a_group_stride < a_group)) return NRV_ERR_SHAPE;
+    const int splits = tn_splits(M, N, T);
+    const int64_t kt_total = nrv_cdiv(T, BK);
+    const int kt_per_split = (int)nrv_cdiv(kt_total, splits);
+    // per-workgroup operand windows must stay below 2 GiB of byte offset
+    const int64_t a_rows = a_group > 0 ? (int64_t)kt_per_split * BK * a_group_stride / a_group + a_group_stride : (int64_t)kt_per_split * BK;
+    if (a_rows * lda * 2 >= 0x7fffffffll || (int64_t)kt_per_split * BK * ldb * 2 >= 0x7fffffffll) return NRV_ERR_SHAPE;
+    const bool direct = splits == 1 && beta == 0.f;
+    const size_t need = direct ? 0 : (size_t)splits * (size_t)M * (size_t)N * 4;
+    if (!direct && (!workspace || workspace_bytes < need)) return NRV_ERR_WORKSPACE;
+    if (!direct && !nrv_aligned16(workspace)) return NRV_ERR_ALIGN;
+
+    GemmTNParams p;
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.lda = lda; p.ldb = ldb; p.T = (int)T;
+    const int tiles_m = (int)nrv_cdiv(M, BM), tiles_n = (int)nrv_cdiv(N, BN);
+    p.tiles_n = tiles_n; p.tiles_mn = tiles_m * tiles_n;
+    p.splits = splits; p.kt_per_split = kt_per_split;
+    p.a_group = (int)a_group; p.a_group_stride = (int)a_group_stride; p.a_row_offset = (int)a_row_offset;
+    p.e.bias = nullptr; p.e.aux = nullptr; p.e.aux_out = nullptr;
+    p.e.ld_aux = 0; p.e.ld_aux_out = 0;
+    p.e.M = (int)M; p.e.N = (int)N; p.e.aux_row_mod = 0;
+    p.e.out_group = 0; p.e.out_group_stride = 0; p.e.out_row_offset = 0;
+    if (direct) { p.e.C = C; p.e.ldc = ldc; p.slab_stride = 0; }
+    else { p.e.C = workspace; p.e.ldc = N; p.slab_stride = (long long)M * N; }
+
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static int attr = set_lds(gemm_tn_kernel);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, p);
+    NRV_CHECK_LAUNCH();
+    if (!direct) {
+        const long long total4 = (long long)M * (N >> 2);
+        int blocks = (int)((total4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s,
+                           static_cast<const float*>(workspace), (long long)M * N, splits, C, (long long)ldc, (int)M, (int)N, beta);
+        NRV_CHECK_LAUNCH();
+    }
+    return 0;
+}

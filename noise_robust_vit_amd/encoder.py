@@ -1,0 +1,359 @@
+"""Encoder-block hot path: forward/backward schedules over the HIP kernels, exposed as autograd Functions.
+
+One transformer block = two "halves", both pre-LayerNorm with a residual add:
+
+    attention half :  x -> LN -> QKV GEMM -> fused attention -> out-proj GEMM (+bias) (+x)
+    MLP half       :  x -> LN -> fc1 GEMM +bias +GELU -> fc2 GEMM +bias (+x)
+
+which is `Transformer.forward` of the reference (simple_vit.py:93-97: x = attn(x) + x; x = ff(x) + x) and
+`EncoderBlock.forward` (vit.py:118-130).  The residual stream is fp32 in HBM; every GEMM operand is bf16;
+LayerNorm statistics, softmax and all accumulation are fp32 (DESIGN.md "Numerics").
+
+Backward is hand-scheduled (no autograd graph inside the stack): per half,
+    dW2 = dY^T H (TN GEMM), dH = dY W2 (NT GEMM on the staged W2^T) with the GELU' epilogue, ...
+and the LayerNorm backward kernel adds the residual-stream gradient and emits both the fp32 stream
+gradient and the bf16 copy the next GEMMs consume.
+
+Nothing here computes with torch ops: torch supplies memory, streams and the autograd boundary.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import kernels as K
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_NONE, NrvError)
+
+Tensor = torch.Tensor
+
+PARAMS_PER_LAYER = 12   # ln1_w ln1_b wqkv bqkv wo bo ln2_w ln2_b w1 b1 w2 b2
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 weight staging: W (fp32 master, nn.Parameter) -> bf16 W and bf16 W^T, refreshed when the
+# parameter's version counter changes (i.e. once per optimizer step).
+# ----------------------------------------------------------------------------------------------
+class WeightCache:
+    def __init__(self) -> None:
+        self._d = {}
+
+    def get(self, w: Tensor, need_t: bool):
+        key = id(w)
+        ent = self._d.get(key)
+        ver = w._version
+        if ent is not None and ent[0] == ver and ent[1] == w.data_ptr() and (ent[3] is not None or not need_t):
+            return ent[2], ent[3]
+        wb, wt = K.cast_transpose(w.detach(), need_t=True)
+        self._d[key] = (ver, w.data_ptr(), wb, wt)
+        return wb, wt
+
+    def clear(self) -> None:
+        self._d.clear()
+
+
+WEIGHTS = WeightCache()
+
+
+@dataclass
+class BlockMeta:
+    heads: int
+    dim_head: int
+    eps: float
+    robust: bool = False
+    # optional gradient sink (data-parallel runtime): grad_out(param) -> (tensor, beta) or None
+    sink: Optional[object] = None
+
+
+def _require_softmax(meta: BlockMeta) -> None:
+    if meta.robust:
+        from .sinkhorn import require_available
+        require_available()
+
+
+def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
+    """(out, beta) for a weight gradient: the sink's flat-buffer view if a sink is attached, else fresh."""
+    if p is None:
+        return None, 0.0
+    if meta.sink is not None:
+        return meta.sink.target(p)
+    return None, 0.0
+
+
+# ----------------------------------------------------------------------------------------------
+# attention half
+# ----------------------------------------------------------------------------------------------
+def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool):
+    """x fp32 [B*N, D] -> (y fp32 [B*N, D], saved)."""
+    H, dh = meta.heads, meta.dim_head
+    xn, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, meta.eps)
+    wqkv_b, _ = WEIGHTS.get(wqkv, True)
+    wo_b, _ = WEIGHTS.get(wo, True)
+    qkv = K.gemm_nt(xn, wqkv_b, out_dtype=torch.bfloat16,
+                    epilogue=EPI_BIAS if bqkv is not None else EPI_NONE, bias=bqkv)
+    scale = dh ** -0.5
+    if meta.robust:
+        from . import sinkhorn
+        o, aux = sinkhorn.attn_fwd(qkv, B, N, H, dh, scale)
+    else:
+        o, aux = K.attn_fwd(qkv, B, N, H, dh, scale)
+    if residual:
+        y = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bo, aux=x)
+    else:
+        y = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS if bo is not None else EPI_NONE, bias=bo)
+    return y, (x, xn, mean, rstd, qkv, o, aux)
+
+
+def attn_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, B: int, N: int, meta: BlockMeta,
+                  ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, want_bf16: bool):
+    """Returns (dx32, dx16|None, [d ln_w, d ln_b, d wqkv, d bqkv, d wo, d bo])."""
+    x, xn, mean, rstd, qkv, o, aux = saved
+    H, dh = meta.heads, meta.dim_head
+    if dy16 is None:
+        dy16 = K.cast_bf16(dy32)
+    _, wo_t = WEIGHTS.get(wo, True)
+    _, wqkv_t = WEIGHTS.get(wqkv, True)
+    # out-proj:  y = o Wo^T (+bo) (+x)
+    t, beta = _grad_target(meta, wo)
+    dwo = K.gemm_tn(dy16, o, out=t, beta=beta)
+    dbo = None
+    if bo is not None:
+        t, beta = _grad_target(meta, bo)
+        dbo = K.colsum(dy16, out=t, beta=beta)
+    do = K.gemm_nt(dy16, wo_t, out_dtype=torch.bfloat16)
+    scale = dh ** -0.5
+    if meta.robust:
+        from . import sinkhorn
+        dqkv = sinkhorn.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
+    else:
+        dqkv = K.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
+    t, beta = _grad_target(meta, wqkv)
+    dwqkv = K.gemm_tn(dqkv, xn, out=t, beta=beta)
+    dbqkv = None
+    if bqkv is not None:
+        t, beta = _grad_target(meta, bqkv)
+        dbqkv = K.colsum(dqkv, out=t, beta=beta)
+    dxn = K.gemm_nt(dqkv, wqkv_t, out_dtype=torch.bfloat16)
+    tg, bg = _grad_target(meta, ln_w)
+    tb, _ = _grad_target(meta, ln_b)
+    dx32, dx16, dg, db = K.layernorm_bwd(dxn, x, ln_w, mean, rstd, dres=dy32 if residual else None,
+                                         want_f32=True, want_bf16=want_bf16, dgamma=tg, dbeta=tb, accumulate=bg != 0.0)
+    return dx32, dx16, [dg, db, dwqkv, dbqkv, dwo, dbo]
+
+
+# ----------------------------------------------------------------------------------------------
+# MLP half
+# ----------------------------------------------------------------------------------------------
+def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residual: bool):
+    xn, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, meta.eps)
+    w1_b, _ = WEIGHTS.get(w1, True)
+    w2_b, _ = WEIGHTS.get(w2, True)
+    T = x.shape[0]
+    u = torch.empty(T, w1.shape[0], dtype=torch.bfloat16, device=x.device)
+    h = K.gemm_nt(xn, w1_b, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=b1, aux_out=u)
+    if residual:
+        y = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=b2, aux=x)
+    else:
+        y = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS if b2 is not None else EPI_NONE, bias=b2)
+    return y, (x, xn, mean, rstd, u, h)
+
+
+def mlp_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, meta: BlockMeta,
+                 ln_w, ln_b, w1, b1, w2, b2, residual: bool, want_bf16: bool):
+    x, xn, mean, rstd, u, h = saved
+    if dy16 is None:
+        dy16 = K.cast_bf16(dy32)
+    _, w2_t = WEIGHTS.get(w2, True)
+    _, w1_t = WEIGHTS.get(w1, True)
+    t, beta = _grad_target(meta, w2)
+    dw2 = K.gemm_tn(dy16, h, out=t, beta=beta)
+    db2 = None
+    if b2 is not None:
+        t, beta = _grad_target(meta, b2)
+        db2 = K.colsum(dy16, out=t, beta=beta)
+    du = K.gemm_nt(dy16, w2_t, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
+    t, beta = _grad_target(meta, w1)
+    dw1 = K.gemm_tn(du, xn, out=t, beta=beta)
+    db1 = None
+    if b1 is not None:
+        t, beta = _grad_target(meta, b1)
+        db1 = K.colsum(du, out=t, beta=beta)
+    dxn = K.gemm_nt(du, w1_t, out_dtype=torch.bfloat16)
+    tg, bg = _grad_target(meta, ln_w)
+    tb, _ = _grad_target(meta, ln_b)
+    dx32, dx16, dg, db = K.layernorm_bwd(dxn, x, ln_w, mean, rstd, dres=dy32 if residual else None,
+                                         want_f32=True, want_bf16=want_bf16, dgamma=tg, dbeta=tb, accumulate=bg != 0.0)
+    return dx32, dx16, [dg, db, dw1, db1, dw2, db2]
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd boundary
+# ----------------------------------------------------------------------------------------------
+def _as_stream(x: Tensor):
+    if not x.is_cuda:
+        raise NrvError("noise_robust_vit_amd runs on the MI355X (HIP) device only: move the module and its input "
+                       "to 'cuda'.  There is deliberately no CPU fallback on this path.")
+    if x.dim() != 3:
+        raise NrvError(f"expected (batch, tokens, dim), got {tuple(x.shape)}")
+    B, N, D = x.shape
+    x2 = x.detach().to(torch.float32).contiguous().reshape(B * N, D)
+    return x2, B, N, D
+
+
+def _mask_sink_grads(meta: BlockMeta, grads: List[Optional[Tensor]]) -> List[Optional[Tensor]]:
+    """With a sink attached the kernels already wrote into the sink's buffers: hand autograd nothing."""
+    if meta.sink is None:
+        return grads
+    return [None for _ in grads]
+
+
+class EncoderStackFn(torch.autograd.Function):
+    """depth x (attention half + MLP half) with residuals; params = PARAMS_PER_LAYER tensors per layer."""
+
+    @staticmethod
+    def forward(ctx, x, meta: BlockMeta, *params):
+        _require_softmax(meta)
+        x2, B, N, D = _as_stream(x)
+        depth = len(params) // PARAMS_PER_LAYER
+        saved = []
+        cur = x2
+        for i in range(depth):
+            p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
+            cur, sa = attn_half_fwd(cur, B, N, meta, *p[0:6], residual=True)
+            cur, sm = mlp_half_fwd(cur, meta, *p[6:12], residual=True)
+            saved.append((sa, sm))
+        ctx.meta, ctx.params, ctx.saved_blocks, ctx.shape = meta, params, saved, (B, N, D)
+        return cur.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        meta, params, saved = ctx.meta, ctx.params, ctx.saved_blocks
+        B, N, D = ctx.shape
+        depth = len(params) // PARAMS_PER_LAYER
+        d32 = dy.to(torch.float32).contiguous().reshape(B * N, D)
+        d16 = None
+        grads: List[Optional[Tensor]] = [None] * len(params)
+        for i in reversed(range(depth)):
+            p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
+            sa, sm = saved[i]
+            d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True)
+            d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0)
+            grads[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = ga + gm
+            saved[i] = None                                  # free this block's activations early
+            if meta.sink is not None:
+                meta.sink.layer_done(i, [q for q in p if q is not None])
+        grads = _mask_sink_grads(meta, grads)
+        return (d32.reshape(B, N, D), None, *grads)
+
+
+class AttnHalfFn(torch.autograd.Function):
+    """Stand-alone `Attention.forward` (simple_vit.py:64-76): LN -> QKV -> attention -> out-proj, no residual."""
+
+    @staticmethod
+    def forward(ctx, x, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo):
+        _require_softmax(meta)
+        x2, B, N, D = _as_stream(x)
+        y, saved = attn_half_fwd(x2, B, N, meta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual=False)
+        ctx.meta, ctx.params, ctx.saved_half, ctx.shape = meta, (ln_w, ln_b, wqkv, bqkv, wo, bo), saved, (B, N, D)
+        return y.reshape(B, N, wo.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, D = ctx.shape
+        d32 = dy.to(torch.float32).contiguous().reshape(B * N, -1)
+        dx32, _, g = attn_half_bwd(d32, None, ctx.saved_half, B, N, ctx.meta, *ctx.params, residual=False, want_bf16=False)
+        return (dx32.reshape(B, N, D), None, *_mask_sink_grads(ctx.meta, g))
+
+
+class MlpHalfFn(torch.autograd.Function):
+    """Stand-alone `FeedForward.forward` (simple_vit.py:44-45): LN -> Linear -> GELU -> Linear, no residual."""
+
+    @staticmethod
+    def forward(ctx, x, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2):
+        x2, B, N, D = _as_stream(x)
+        y, saved = mlp_half_fwd(x2, meta, ln_w, ln_b, w1, b1, w2, b2, residual=False)
+        ctx.meta, ctx.params, ctx.saved_half, ctx.shape = meta, (ln_w, ln_b, w1, b1, w2, b2), saved, (B, N, D)
+        return y.reshape(B, N, w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, D = ctx.shape
+        d32 = dy.to(torch.float32).contiguous().reshape(B * N, -1)
+        dx32, _, g = mlp_half_bwd(d32, None, ctx.saved_half, ctx.meta, *ctx.params, residual=False, want_bf16=False)
+        return (dx32.reshape(B, N, D), None, *_mask_sink_grads(ctx.meta, g))
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """Patch unfold + projection + bias + positional table, written straight into the fp32 residual stream.
+
+    SimpleViT (simple_vit.py:126-131,141-143): layout (p1 p2 c), pos = fixed sincos table [n, D], cls_slot = 0.
+    VisionTransformer (vit.py:237-242,308-333,341-342, Encoder :174): layout (c p1 p2) with the Conv2d weight
+    viewed [D, C*p*p]; cls_slot = 1 leaves row 0 of every sample for `class_token + pos[0]` and adds pos[1:].
+    """
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, pos, cls_token, patch: int, layout: int, sink):
+        if not img.is_cuda:
+            raise NrvError("noise_robust_vit_amd runs on the MI355X (HIP) device only: move the module and its "
+                           "input to 'cuda'.  There is deliberately no CPU fallback on this path.")
+        if img.requires_grad:
+            raise NrvError("gradient w.r.t. the input image is not part of this hot path")
+        Bn, C, H, W = img.shape
+        n = (H // patch) * (W // patch)
+        D = weight.shape[0]
+        w2d = weight.reshape(D, -1)
+        patches = K.patch_unfold(img.detach(), patch, layout)
+        wb, _ = WEIGHTS.get(weight if weight.dim() == 2 else w2d, False) if weight.dim() == 2 else (K.cast_transpose(w2d.detach(), False)[0], None)
+        cls_slot = 0 if cls_token is None else 1
+        S = n + cls_slot
+        out = torch.empty(Bn * S, D, dtype=torch.float32, device=img.device)
+        pos2 = pos.detach().reshape(-1, D).to(torch.float32)
+        if cls_slot:
+            K.gemm_nt(patches, wb, epilogue=EPI_BIAS_RESIDUAL, bias=bias.detach() if bias is not None else None,
+                      aux=pos2[1:], aux_row_mod=n, out=out, out_group=n, out_group_stride=S, out_row_offset=1)
+            out.view(Bn, S, D)[:, 0] = (cls_token.detach().reshape(D) + pos2[0])      # B*D elements: not the hot path
+        else:
+            K.gemm_nt(patches, wb, epilogue=EPI_BIAS_RESIDUAL, bias=bias.detach() if bias is not None else None,
+                      aux=pos2, aux_row_mod=n, out=out)
+        ctx.save_for_backward(patches)
+        ctx.cfg = (Bn, n, S, D, cls_slot, weight.shape, bias is not None, pos.shape, pos.requires_grad,
+                   cls_token is not None and cls_token.requires_grad, sink, weight, bias)
+        return out.reshape(Bn, S, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        Bn, n, S, D, cls_slot, wshape, has_bias, pos_shape, pos_grad, cls_grad, sink, weight, bias = ctx.cfg
+        d32 = dy.to(torch.float32).contiguous().reshape(Bn * S, D)
+        d16 = K.cast_bf16(d32)
+        tw, bw = (sink.target(weight) if sink is not None else (None, 0.0))
+        if tw is not None:
+            tw = tw.reshape(D, -1)
+        if cls_slot:
+            dw = K.gemm_tn(d16, patches, out=tw, beta=bw, a_group=n, a_group_stride=S, a_row_offset=1, T=Bn * n)
+        else:
+            dw = K.gemm_tn(d16, patches, out=tw, beta=bw)
+        # positional-table / class-token / bias gradients are [S, D]-sized reductions over the batch
+        dsum = K.colsum(d16.reshape(Bn, S * D)).reshape(S, D)
+        dpos = dsum.reshape(pos_shape) if pos_grad else None
+        dcls = dsum[0].reshape(1, 1, D) if cls_grad else None
+        db = None
+        if has_bias:
+            db = dsum[cls_slot:].sum(0)
+            if sink is not None:
+                tb, bb = sink.target(bias)
+                tb.copy_(db) if bb == 0.0 else tb.add_(db)
+        if sink is not None:
+            sink.layer_done(-1, [weight] + ([bias] if has_bias else []))
+            return (None, None, None, dpos, dcls, None, None, None)
+        return (None, dw.reshape(wshape), db, dpos, dcls, None, None, None)
+
+
+def flat_layer_params(layers: Sequence[Sequence[Optional[Tensor]]]) -> List[Optional[Tensor]]:
+    out: List[Optional[Tensor]] = []
+    for lp in layers:
+        if len(lp) != PARAMS_PER_LAYER:
+            raise ValueError("each layer needs PARAMS_PER_LAYER entries")
+        out.extend(lp)
+    return out

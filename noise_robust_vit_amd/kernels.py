@@ -1,0 +1,250 @@
+"""Tensor-level wrappers over the C ABI (include/nrv.h).  No autograd, no fallbacks.
+
+PyTorch is used for device memory (caching allocator) and the current HIP stream only; every
+arithmetic result comes from a kernel in libnrv_hip.so.  All tensors must live on a HIP device
+(`tensor.is_cuda`), be contiguous in their last dimension and 16-byte aligned.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_NONE, NRV_BF16, NRV_F32,
+                   PATCH_CP1P2, PATCH_P1P2C, NrvError, check)
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise NrvError(f"{name} must be on the MI355X (HIP) device; this path has no CPU implementation")
+
+
+def _dt(t: Tensor, name: str) -> int:
+    if t.dtype == torch.float32:
+        return NRV_F32
+    if t.dtype == torch.bfloat16:
+        return NRV_BF16
+    raise NrvError(f"{name}: dtype {t.dtype} not supported (fp32 or bf16)")
+
+
+def _bf16(t: Tensor, name: str) -> None:
+    _dev(t, name)
+    if t.dtype != torch.bfloat16:
+        raise NrvError(f"{name} must be bf16, got {t.dtype}")
+
+
+def _f32(t: Tensor, name: str) -> None:
+    _dev(t, name)
+    if t.dtype != torch.float32:
+        raise NrvError(f"{name} must be fp32, got {t.dtype}")
+
+
+def _rows2d(t: Tensor, name: str) -> Tuple[int, int, int]:
+    """(rows, cols, ld) of a 2-D view with unit stride in the last dim."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise NrvError(f"{name} must be 2-D with contiguous rows, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------------
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+    """x [rows, dim] fp32|bf16 -> (y bf16, mean fp32, rstd fp32).  nn.LayerNorm (simple_vit.py:38,54; vit.py:104,115)."""
+    _dev(x, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    x = x.contiguous()
+    rows, dim = x.shape
+    y = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().nrv_layernorm_fwd(x.data_ptr(), _dt(x, "x"), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                        mean.data_ptr(), rstd.data_ptr(), rows, dim, float(eps), _stream()),
+          "nrv_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
+                  want_f32: bool = True, want_bf16: bool = False,
+                  dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None, accumulate: bool = False):
+    """Returns (dx_f32|None, dx_bf16|None, dgamma, dbeta); dx = dres + LN'(dy)."""
+    _bf16(dy, "dy"); _dev(x, "x"); _f32(gamma, "gamma")
+    rows, dim = x.shape
+    lib = _lib.load()
+    dx32 = torch.empty(rows, dim, dtype=torch.float32, device=x.device) if want_f32 else None
+    dx16 = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    if dgamma is None:
+        dgamma = torch.empty(dim, dtype=torch.float32, device=x.device); accumulate = False
+    if dbeta is None:
+        dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
+    wsb = lib.nrv_layernorm_bwd_workspace(rows, dim)
+    ws = _workspace(wsb, x.device)
+    check(lib.nrv_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _dt(x, "x"), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                _ptr(dres), _dt(dres, "dres") if dres is not None else 0,
+                                _ptr(dx32), _ptr(dx16), dgamma.data_ptr(), dbeta.data_ptr(), int(bool(accumulate)),
+                                ws.data_ptr(), ws.numel(), rows, dim, _stream()),
+          "nrv_layernorm_bwd")
+    return dx32, dx16, dgamma, dbeta
+
+
+def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, epilogue: int = EPI_NONE,
+            bias: Optional[Tensor] = None, aux: Optional[Tensor] = None, aux_row_mod: int = 0,
+            aux_out: Optional[Tensor] = None, out: Optional[Tensor] = None,
+            out_group: int = 0, out_group_stride: int = 0, out_row_offset: int = 0) -> Tensor:
+    """C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue (include/nrv.h nrv_gemm_nt_bf16)."""
+    _bf16(A, "A"); _bf16(B, "B")
+    M, K, lda = _rows2d(A, "A")
+    N, K2, ldb = _rows2d(B, "B")
+    if K != K2:
+        raise NrvError(f"gemm_nt: K mismatch {K} vs {K2}")
+    if out is None:
+        if out_group:
+            raise NrvError("gemm_nt: an output row remap needs a caller-provided `out`")
+        out = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    _, _, ldc = _rows2d(out, "out")
+    ld_aux = 0
+    if aux is not None:
+        _dev(aux, "aux")
+        _, _, ld_aux = _rows2d(aux, "aux")
+    ld_ao = 0
+    if aux_out is not None:
+        _bf16(aux_out, "aux_out")
+        _, _, ld_ao = _rows2d(aux_out, "aux_out")
+    if bias is not None:
+        _f32(bias, "bias")
+    check(_lib.load().nrv_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), _dt(out, "out"), ldc,
+                                       M, N, K, int(epilogue), _ptr(bias),
+                                       _ptr(aux), _dt(aux, "aux") if aux is not None else 0, ld_aux, int(aux_row_mod),
+                                       _ptr(aux_out), ld_ao, int(out_group), int(out_group_stride), int(out_row_offset),
+                                       _stream()),
+          "nrv_gemm_nt_bf16")
+    return out
+
+
+def gemm_tn(A: Tensor, B: Tensor, *, out: Optional[Tensor] = None, beta: float = 0.0,
+            a_group: int = 0, a_group_stride: int = 0, a_row_offset: int = 0, T: Optional[int] = None) -> Tensor:
+    """C[M,N] fp32 = beta*C + sum_t A[t,M] B[t,N]  (weight gradient).  `T` limits the token rows used (default B.shape[0])."""
+    _bf16(A, "A"); _bf16(B, "B")
+    Ta, M, lda = _rows2d(A, "A")
+    Tb, N, ldb = _rows2d(B, "B")
+    T = Tb if T is None else T
+    if a_group == 0 and Ta != Tb:
+        raise NrvError(f"gemm_tn: token count mismatch {Ta} vs {Tb}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+        beta = 0.0
+    _f32(out, "out")
+    _, _, ldc = _rows2d(out, "out")
+    lib = _lib.load()
+    ws = _workspace(lib.nrv_gemm_tn_workspace(M, N, T), A.device)
+    check(lib.nrv_gemm_tn_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, T, float(beta),
+                               int(a_group), int(a_group_stride), int(a_row_offset), ws.data_ptr(), ws.numel(), _stream()),
+          "nrv_gemm_tn_bf16")
+    return out
+
+
+def colsum(X: Tensor, *, out: Optional[Tensor] = None, beta: float = 0.0) -> Tensor:
+    """out[n] = beta*out[n] + sum_t X[t,n]  (bias gradient)."""
+    _bf16(X, "X")
+    T, N, ld = _rows2d(X, "X")
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+        beta = 0.0
+    lib = _lib.load()
+    ws = _workspace(lib.nrv_colsum_workspace(T, N), X.device)
+    check(lib.nrv_colsum_bf16(X.data_ptr(), ld, out.data_ptr(), T, N, float(beta), ws.data_ptr(), ws.numel(), _stream()),
+          "nrv_colsum_bf16")
+    return out
+
+
+def attn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
+    """qkv bf16 [B*N, 3*H*dh] -> (out bf16 [B*N, H*dh], lse fp32 [B,H,N]).  simple_vit.py:68-75."""
+    _bf16(qkv, "qkv")
+    if not qkv.is_contiguous() or qkv.numel() != B * N * 3 * H * dh:
+        raise NrvError("attn_fwd: qkv must be contiguous [B*N, 3*H*dh]")
+    out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().nrv_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, dh, float(scale), _stream()),
+          "nrv_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+    _bf16(qkv, "qkv"); _bf16(out, "out"); _bf16(dout, "dout"); _f32(lse, "lse")
+    if not (qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()):
+        raise NrvError("attn_bwd: operands must be contiguous")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B * H * N, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().nrv_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                   delta.data_ptr(), B, N, H, dh, float(scale), _stream()),
+          "nrv_attn_bwd")
+    return dqkv
+
+
+def patch_unfold(img: Tensor, p: int, layout: int) -> Tensor:
+    """img [B,C,H,W] fp32|bf16 -> patches bf16 [B*(H/p)*(W/p), C*p*p]."""
+    _dev(img, "img")
+    img = img.contiguous()
+    B, C, H, W = img.shape
+    out = torch.empty(B * (H // p) * (W // p), C * p * p, dtype=torch.bfloat16, device=img.device)
+    check(_lib.load().nrv_patch_unfold(img.data_ptr(), _dt(img, "img"), out.data_ptr(), B, C, H, W, p, layout, _stream()),
+          "nrv_patch_unfold")
+    return out
+
+
+def cast_transpose(w: Tensor, need_t: bool = True):
+    """w fp32 [R,C] -> (w_bf16 [R,C], wT_bf16 [C,R] | None)."""
+    _f32(w, "w")
+    w = w.contiguous()
+    R, C = w.shape
+    wb = torch.empty(R, C, dtype=torch.bfloat16, device=w.device)
+    wt = torch.empty(C, R, dtype=torch.bfloat16, device=w.device) if need_t else None
+    check(_lib.load().nrv_cast_transpose(w.data_ptr(), wb.data_ptr(), _ptr(wt), R, C, _stream()), "nrv_cast_transpose")
+    return wb, wt
+
+
+def cast_bf16(x: Tensor) -> Tensor:
+    _f32(x, "x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().nrv_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "nrv_cast_f32_bf16")
+    return y
+
+
+def gather_rows(src: Tensor, index: Tensor) -> Tensor:
+    """out[r] = src[index[r]]; src fp32 [R, dim], index int64 [rows_out]."""
+    _f32(src, "src"); _dev(index, "index")
+    src = src.contiguous(); index = index.contiguous()
+    out = torch.empty(index.numel(), src.shape[1], dtype=torch.float32, device=src.device)
+    check(_lib.load().nrv_gather_rows_f32(src.data_ptr(), index.data_ptr(), out.data_ptr(), index.numel(), src.shape[1], _stream()),
+          "nrv_gather_rows_f32")
+    return out
+
+
+def scatter_rows(dout: Tensor, index: Tensor, rows_src: int) -> Tensor:
+    """dsrc = zeros[rows_src, dim]; dsrc[index[r]] = dout[r]  (indices unique)."""
+    _f32(dout, "dout"); _dev(index, "index")
+    dout = dout.contiguous(); index = index.contiguous()
+    dsrc = torch.zeros(rows_src, dout.shape[1], dtype=torch.float32, device=dout.device)
+    check(_lib.load().nrv_scatter_rows_f32(dout.data_ptr(), index.data_ptr(), dsrc.data_ptr(), index.numel(), dout.shape[1], _stream()),
+          "nrv_scatter_rows_f32")
+    return dsrc
+
+
+def probe(which: int, data: Tensor, n_out: int) -> Tensor:
+    _dev(data, "data")
+    out = torch.zeros(n_out, dtype=torch.float32, device=data.device)
+    check(_lib.load().nrv_probe(which, data.data_ptr(), out.data_ptr(), data.numel() * data.element_size(), _stream()), "nrv_probe")
+    return out

@@ -1,0 +1,312 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against a plain PyTorch fp32 reference of the
+same op evaluated on the SAME bf16-rounded operands (so the only differences are fp32 summation order and
+the final store rounding).  Tolerances are written next to each check.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _k():
+    from noise_robust_vit_amd import kernels
+    return kernels
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.float(); b = b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+# ------------------------------------------------------------------ hardware-assumption probes
+def test_probe_mfma_lane_map(dev):
+    k = _k()
+    A = rnd((16, 32), dev, 1)
+    # asymmetric B (cdna guide: always check with asymmetric B)
+    B = (torch.arange(32 * 16, dtype=torch.float32).reshape(32, 16) % 7 - 3).to(torch.bfloat16).to(dev)
+    data = torch.cat([A.reshape(-1), B.t().contiguous().reshape(-1)])
+    out = k.probe(0, data, 256).reshape(16, 16)
+    ref = A.float() @ B.float()
+    assert rel_err(out, ref) < 1e-6, (out, ref)
+
+
+def test_probe_transposed_lds_read(dev):
+    k = _k()
+    img = torch.arange(16 * 64, dtype=torch.float32).reshape(16, 64)
+    img = (img % 251).to(torch.bfloat16).to(dev)
+    out = k.probe(1, img.reshape(-1), 256).reshape(64, 4).cpu()
+    ref = torch.empty(64, 4)
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        for e in range(4):
+            ref[lane, e] = img[4 * g + e, i].float().item()
+    assert torch.equal(out, ref), (out, ref)
+
+
+def test_probe_lds_dma_linear_and_oob_zero(dev):
+    k = _k()
+    src = (torch.arange(512, dtype=torch.float32) % 199 + 1).to(torch.bfloat16).to(dev)     # 1024 bytes
+    out = k.probe(2, src[:384 + 64], 512).cpu()         # 896 bytes of records
+    ref = src.float().cpu().clone()
+    ref[384:] = 0.0                                      # lanes 48..63 were out of range -> zero fill
+    assert torch.equal(out, ref), (out[376:400], ref[376:400])
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,dim", [(32, 192), (1000, 768), (777, 384), (64, 1024), (5, 64), (130, 4096)])
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd_bwd(dev, rows, dim, xdt):
+    k = _k()
+    x = rnd((rows, dim), dev, 3, 2.0, torch.float32).add_(0.5).to(xdt)
+    gamma = rnd((dim,), dev, 4, 0.5, torch.float32) + 1.0
+    beta = rnd((dim,), dev, 5, 0.5, torch.float32)
+    eps = 1e-5
+    y, mean, rstd = k.layernorm_fwd(x, gamma, beta, eps)
+    xr = x.float().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (dim,), gr, br, eps)
+    # fp32 math, one bf16 rounding on store: |err| <= 2^-8 relative per element
+    assert ((y.float() - yr).abs() <= yr.abs() * 2 ** -8 + 1e-6).all()
+    assert rel_err(mean, x.float().mean(1)) < 1e-5
+    dy = rnd((rows, dim), dev, 6)
+    dres = rnd((rows, dim), dev, 7, 1.0, torch.float32)
+    yr.backward(dy.float())
+    dx32, dx16, dg, db = k.layernorm_bwd(dy, x, gamma, mean, rstd, dres=dres, want_f32=True, want_bf16=True)
+    ref_dx = xr.grad + dres
+    assert rel_err(dx32, ref_dx) < 2e-5, rel_err(dx32, ref_dx)
+    assert rel_err(dx16, ref_dx) < 2 ** -7
+    assert rel_err(dg, gr.grad) < 2e-5 * math.sqrt(rows), rel_err(dg, gr.grad)
+    assert rel_err(db, br.grad) < 2e-5 * math.sqrt(rows)
+    # accumulate=True adds to existing grads; no residual
+    dx32b, _, dg2, db2 = k.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=dg.clone(), dbeta=db.clone(), accumulate=True)
+    assert rel_err(dg2, 2 * gr.grad) < 1e-4 and rel_err(db2, 2 * br.grad) < 1e-4
+    assert rel_err(dx32b, xr.grad) < 2e-5
+
+
+# ------------------------------------------------------------------ GEMM NT
+NT_SHAPES = [(32, 192, 192), (256, 256, 64), (300, 576, 192), (1000, 768, 768), (513, 384, 1536),
+             (2048, 2304, 768), (257, 104, 72), (1024, 3072, 768), (512, 768, 3072)]
+
+
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_gemm_nt_plain(dev, M, N, K):
+    k = _k()
+    A = rnd((M, K), dev, 10)
+    B = rnd((N, K), dev, 11)
+    ref = A.float() @ B.float().t()
+    c32 = k.gemm_nt(A, B, out_dtype=torch.float32)
+    # identical operands, fp32 accumulate: only the summation order differs
+    assert rel_err(c32, ref) < 1e-5 * math.sqrt(K), rel_err(c32, ref)
+    c16 = k.gemm_nt(A, B, out_dtype=torch.bfloat16)
+    assert ((c16.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-3 * ref.abs().max()).all()
+
+
+def test_gemm_nt_identity_asymmetric(dev):
+    """A = I with an asymmetric B catches a transposed C write (guide §3)."""
+    k = _k()
+    M = N = K = 256
+    A = torch.eye(M, dtype=torch.bfloat16, device=dev)
+    B = (torch.arange(N * K, device=dev, dtype=torch.float32).reshape(N, K) % 13 - 6).to(torch.bfloat16)
+    c = k.gemm_nt(A, B, out_dtype=torch.float32)
+    assert torch.equal(c, B.float().t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 576, 192), (1000, 768, 768), (512, 3072, 768)])
+def test_gemm_nt_epilogues(dev, M, N, K):
+    k = _k()
+    from noise_robust_vit_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU
+    A = rnd((M, K), dev, 20, 0.5)
+    B = rnd((N, K), dev, 21, 0.1)
+    bias = rnd((N,), dev, 22, 1.0, torch.float32)
+    acc = A.float() @ B.float().t()
+    # bias
+    c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS, bias=bias)
+    assert rel_err(c, acc + bias) < 1e-5 * math.sqrt(K)
+    # bias + exact-erf GELU, pre-activation saved
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    h = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_GELU, bias=bias, aux_out=u)
+    ref_h = torch.nn.functional.gelu(acc + bias)            # erf form
+    assert (h - ref_h).abs().max().item() < 3e-6 * (1 + ref_h.abs().max().item())
+    assert ((u.float() - (acc + bias)).abs() <= (acc + bias).abs() * 2 ** -8 + 1e-5).all()
+    # bias + residual, fp32 stream
+    res = rnd((M, N), dev, 23, 1.0, torch.float32)
+    c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bias, aux=res)
+    assert rel_err(c, acc + bias + res) < 1e-5 * math.sqrt(K)
+    # residual without bias, bf16 stream, broadcast rows (positional table)
+    tab = rnd((50, N), dev, 24, 1.0, torch.bfloat16)
+    c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, aux=tab, aux_row_mod=50)
+    idx = torch.arange(M, device=dev) % 50
+    assert rel_err(c, acc + tab.float()[idx]) < 1e-5 * math.sqrt(K)
+    # dGELU
+    uu = rnd((M, N), dev, 25, 1.5)
+    c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_DGELU, aux=uu)
+    uf = uu.float().requires_grad_(True)
+    torch.nn.functional.gelu(uf).sum().backward()
+    assert (c - acc * uf.grad).abs().max().item() < 1e-5 * math.sqrt(K) * acc.abs().max().item()
+
+
+def test_gemm_nt_row_remap(dev):
+    """class-token slot: result row m lands at (m // 196) * 197 + m % 196 + 1 (vit.py:341-342)."""
+    k = _k()
+    from noise_robust_vit_amd._lib import EPI_BIAS_RESIDUAL
+    Bt, G, D, K = 3, 196, 128, 64
+    A = rnd((Bt * G, K), dev, 30)
+    W = rnd((D, K), dev, 31)
+    pos = rnd((G + 1, D), dev, 32, 1.0, torch.float32)
+    bias = rnd((D,), dev, 33, 1.0, torch.float32)
+    out = torch.zeros(Bt * (G + 1), D, dtype=torch.float32, device=dev)
+    k.gemm_nt(A, W, epilogue=EPI_BIAS_RESIDUAL, bias=bias, aux=pos[1:], aux_row_mod=G, out=out,
+              out_group=G, out_group_stride=G + 1, out_row_offset=1)
+    ref = torch.zeros(Bt, G + 1, D, device=dev)
+    ref[:, 1:] = (A.float() @ W.float().t() + bias).reshape(Bt, G, D) + pos[1:]
+    assert rel_err(out.reshape(Bt, G + 1, D), ref) < 1e-5
+
+
+# ------------------------------------------------------------------ GEMM TN / colsum
+@pytest.mark.parametrize("T,M,N", [(32, 192, 192), (64, 256, 256), (1000, 768, 768), (3000, 576, 192),
+                                   (5000, 3072, 768), (777, 104, 72), (4096, 768, 3072), (50, 384, 1536)])
+def test_gemm_tn(dev, T, M, N):
+    k = _k()
+    A = rnd((T, M), dev, 40)
+    B = rnd((T, N), dev, 41)
+    ref = A.float().t() @ B.float()
+    c = k.gemm_tn(A, B)
+    assert rel_err(c, ref) < 2e-5 * math.sqrt(T), rel_err(c, ref)
+    c2 = k.gemm_tn(A, B, out=c.clone(), beta=1.0)
+    assert rel_err(c2, 2 * ref) < 2e-5 * math.sqrt(T)
+
+
+def test_gemm_tn_identity_asymmetric(dev):
+    k = _k()
+    T = M = 256
+    N = 256
+    A = torch.eye(T, dtype=torch.bfloat16, device=dev)
+    B = (torch.arange(T * N, device=dev, dtype=torch.float32).reshape(T, N) % 11 - 5).to(torch.bfloat16)
+    c = k.gemm_tn(A, B)
+    assert torch.equal(c, B.float())
+
+
+def test_gemm_tn_row_remap(dev):
+    k = _k()
+    Bt, G, D, F = 3, 196, 128, 64
+    dY = rnd((Bt * (G + 1), D), dev, 42)
+    P = rnd((Bt * G, F), dev, 43)
+    c = k.gemm_tn(dY, P, a_group=G, a_group_stride=G + 1, a_row_offset=1, T=Bt * G)
+    ref = dY.float().reshape(Bt, G + 1, D)[:, 1:].reshape(-1, D).t() @ P.float()
+    assert rel_err(c, ref) < 1e-4
+
+
+@pytest.mark.parametrize("T,N", [(32, 192), (1000, 768), (4097, 3072), (3, 64)])
+def test_colsum(dev, T, N):
+    k = _k()
+    X = rnd((T, N), dev, 50)
+    out = k.colsum(X)
+    assert rel_err(out, X.float().sum(0)) < 1e-5 * math.sqrt(T)
+    out2 = k.colsum(X, out=out.clone(), beta=1.0)
+    assert rel_err(out2, 2 * X.float().sum(0)) < 1e-5 * math.sqrt(T)
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(qkv, B, N, H, dh, scale):
+    q, k, v = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)     # [3][B,H,N,dh]
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = torch.softmax(s, dim=-1)
+    o = p @ v
+    return o.permute(0, 2, 1, 3).reshape(B * N, H * dh), torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,N,H", [(8, 4, 3), (2, 196, 3), (2, 197, 2), (3, 49, 2), (1, 256, 1), (2, 33, 1), (1, 1, 1)])
+def test_attention_fwd_bwd(dev, B, N, H):
+    k = _k()
+    dh = 64
+    scale = dh ** -0.5
+    qkv = rnd((B * N, 3 * H * dh), dev, 60, 1.0)
+    out, lse = k.attn_fwd(qkv, B, N, H, dh, scale)
+    qr = qkv.float().requires_grad_(True)
+    ref_o, ref_lse = attn_ref(qr, B, N, H, dh, scale)
+    # P is fed to the PV product in bf16 and the output is stored in bf16: 2^-8 relative each
+    assert (out.float() - ref_o).abs().max().item() < 2 ** -7 * ref_o.abs().max().item() + 1e-3, \
+        (out.float() - ref_o).abs().max().item()
+    assert (lse - ref_lse).abs().max().item() < 1e-4
+    dout = rnd((B * N, H * dh), dev, 61, 1.0)
+    ref_o.backward(dout.float())
+    dqkv = k.attn_bwd(qkv, out, dout, lse, B, N, H, dh, scale)
+    err = (dqkv.float() - qr.grad).abs().max().item() / qr.grad.abs().max().item()
+    assert err < 2e-2, err
+    cos = torch.nn.functional.cosine_similarity(dqkv.float().reshape(-1), qr.grad.reshape(-1), dim=0).item()
+    assert cos > 0.9995, cos
+
+
+def test_attention_large_logits(dev):
+    """softmax stability: scores of magnitude ~100 must not overflow (max subtraction)."""
+    k = _k()
+    B, N, H, dh = 1, 64, 1, 64
+    qkv = rnd((B * N, 3 * H * dh), dev, 62, 4.0)
+    out, lse = k.attn_fwd(qkv, B, N, H, dh, 1.0)
+    ref_o, ref_lse = attn_ref(qkv, B, N, H, dh, 1.0)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert (lse - ref_lse).abs().max().item() < 1e-3 * ref_lse.abs().max().item()
+    assert (out.float() - ref_o).abs().max().item() < 2 ** -6 * ref_o.abs().max().item()
+
+
+# ------------------------------------------------------------------ data movement
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patch_unfold(dev, layout, dt):
+    k = _k()
+    B, C, H, W, p = 3, 3, 64, 48, 16
+    img = rnd((B, C, H, W), dev, 70, 1.0, dt)
+    out = k.patch_unfold(img, p, layout)
+    t = img.reshape(B, C, H // p, p, W // p, p)
+    if layout == 0:
+        ref = t.permute(0, 2, 4, 3, 5, 1)        # b h w p1 p2 c  (simple_vit.py:126-129)
+    else:
+        ref = t.permute(0, 2, 4, 1, 3, 5)        # b h w c p1 p2  (Conv2d weight order)
+    ref = ref.reshape(B * (H // p) * (W // p), C * p * p).to(torch.bfloat16)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("R,C", [(192, 576), (768, 3072), (100, 72), (1000, 192)])
+def test_cast_transpose(dev, R, C):
+    k = _k()
+    w = rnd((R, C), dev, 80, 1.0, torch.float32)
+    wb, wt = k.cast_transpose(w)
+    assert torch.equal(wb, w.to(torch.bfloat16))
+    assert torch.equal(wt, w.to(torch.bfloat16).t().contiguous())
+    wb2, none = k.cast_transpose(w, need_t=False)
+    assert none is None and torch.equal(wb2, wb)
+    x = rnd((1003,), dev, 81, 1.0, torch.float32)
+    assert torch.equal(k.cast_bf16(x), x.to(torch.bfloat16))
+
+
+def test_gather_scatter_rows(dev):
+    k = _k()
+    src = rnd((40, 192), dev, 90, 1.0, torch.float32)
+    idx = torch.randperm(40, device=dev)[:10]
+    g = k.gather_rows(src, idx)
+    assert torch.equal(g, src[idx])
+    s = k.scatter_rows(g, idx, 40)
+    ref = torch.zeros_like(src); ref[idx] = g
+    assert torch.equal(s, ref)
+
+
+# ------------------------------------------------------------------ error behaviour (no silent fallbacks)
+def test_errors_are_loud(dev):
+    k = _k()
+    from noise_robust_vit_amd._lib import NrvError
+    A = rnd((64, 60), dev, 1)           # K % 8 != 0
+    with pytest.raises(NrvError):
+        k.gemm_nt(A, A)
+    with pytest.raises(NrvError):
+        k.gemm_nt(A.cpu(), A.cpu())     # CPU tensors are refused, not silently computed
+    qkv = rnd((300, 3 * 64), dev, 2)
+    with pytest.raises(NrvError):
+        k.attn_fwd(qkv, 1, 300, 1, 64, 0.125)   # N > 256 unsupported
