@@ -45,7 +45,10 @@ class WeightCache:
         ver = w._version
         if ent is not None and ent[0] == ver and ent[1] == w.data_ptr() and (ent[3] is not None or not need_t):
             return ent[2], ent[3]
-        wb, wt = K.cast_transpose(w.detach(), need_t=True)
+        w2 = w.detach()
+        if w2.dim() != 2:                       # Conv2d patch-embed weight [D, C, p, p] viewed as [D, C*p*p]
+            w2 = w2.reshape(w2.shape[0], -1)
+        wb, wt = K.cast_transpose(w2, need_t=True)
         self._d[key] = (ver, w.data_ptr(), wb, wt)
         return wb, wt
 
@@ -302,9 +305,8 @@ class PatchEmbedFn(torch.autograd.Function):
         Bn, C, H, W = img.shape
         n = (H // patch) * (W // patch)
         D = weight.shape[0]
-        w2d = weight.reshape(D, -1)
         patches = K.patch_unfold(img.detach(), patch, layout)
-        wb, _ = WEIGHTS.get(weight if weight.dim() == 2 else w2d, False) if weight.dim() == 2 else (K.cast_transpose(w2d.detach(), False)[0], None)
+        wb, _ = WEIGHTS.get(weight, False)
         cls_slot = 0 if cls_token is None else 1
         S = n + cls_slot
         out = torch.empty(Bn * S, D, dtype=torch.float32, device=img.device)
@@ -334,16 +336,19 @@ class PatchEmbedFn(torch.autograd.Function):
             dw = K.gemm_tn(d16, patches, out=tw, beta=bw, a_group=n, a_group_stride=S, a_row_offset=1, T=Bn * n)
         else:
             dw = K.gemm_tn(d16, patches, out=tw, beta=bw)
-        # positional-table / class-token / bias gradients are [S, D]-sized reductions over the batch
-        dsum = K.colsum(d16.reshape(Bn, S * D)).reshape(S, D)
-        dpos = dsum.reshape(pos_shape) if pos_grad else None
-        dcls = dsum[0].reshape(1, 1, D) if cls_grad else None
-        db = None
-        if has_bias:
-            db = dsum[cls_slot:].sum(0)
-            if sink is not None:
-                tb, bb = sink.target(bias)
-                tb.copy_(db) if bb == 0.0 else tb.add_(db)
+        # positional-table / class-token / bias gradients are reductions of dy over the batch
+        dpos = dcls = db = None
+        if pos_grad or cls_grad or cls_slot:
+            dsum = K.colsum(d16.reshape(Bn, S * D)).reshape(S, D)
+            dpos = dsum.reshape(pos_shape) if pos_grad else None
+            dcls = dsum[0].reshape(1, 1, D) if cls_grad else None
+            if has_bias:
+                db = dsum[cls_slot:].sum(0)          # [S, D] -> [D]: outside the hot path
+        elif has_bias:
+            db = K.colsum(d16)
+        if has_bias and sink is not None:
+            tb, bb = sink.target(bias)
+            tb.copy_(db) if bb == 0.0 else tb.add_(db)
         if sink is not None:
             sink.layer_done(-1, [weight] + ([bias] if has_bias else []))
             return (None, None, None, dpos, dcls, None, None, None)

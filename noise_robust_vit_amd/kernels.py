@@ -62,6 +62,52 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): HIP events on the stream the kernel runs on
+# ----------------------------------------------------------------------------------------------
+_PROF = None
+
+
+class LaunchProfile:
+    """Collects (kernel class, algorithmic FLOPs, algorithmic bytes, start event, end event) per C-ABI call."""
+
+    def __init__(self) -> None:
+        self.records = []
+
+    def __enter__(self):
+        global _PROF
+        _PROF = self
+        return self
+
+    def __exit__(self, *exc):
+        global _PROF
+        _PROF = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, s, e in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+def _run(name: str, flops: float, nbytes: float, call, what: str) -> None:
+    if _PROF is None:
+        check(call(), what)
+        return
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    code = call()
+    e.record()
+    check(code, what)
+    _PROF.records.append((name, flops, nbytes, s, e))
+
+
+# ----------------------------------------------------------------------------------------------
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
     """x [rows, dim] fp32|bf16 -> (y bf16, mean fp32, rstd fp32).  nn.LayerNorm (simple_vit.py:38,54; vit.py:104,115)."""
     _dev(x, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
@@ -70,9 +116,11 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
     y = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(_lib.load().nrv_layernorm_fwd(x.data_ptr(), _dt(x, "x"), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                        mean.data_ptr(), rstd.data_ptr(), rows, dim, float(eps), _stream()),
-          "nrv_layernorm_fwd")
+    lib = _lib.load()
+    _run("layernorm_fwd", 0.0, rows * dim * (x.element_size() + 2),
+         lambda: lib.nrv_layernorm_fwd(x.data_ptr(), _dt(x, "x"), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                       mean.data_ptr(), rstd.data_ptr(), rows, dim, float(eps), _stream()),
+         "nrv_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -91,11 +139,14 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
         dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
     wsb = lib.nrv_layernorm_bwd_workspace(rows, dim)
     ws = _workspace(wsb, x.device)
-    check(lib.nrv_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _dt(x, "x"), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                _ptr(dres), _dt(dres, "dres") if dres is not None else 0,
-                                _ptr(dx32), _ptr(dx16), dgamma.data_ptr(), dbeta.data_ptr(), int(bool(accumulate)),
-                                ws.data_ptr(), ws.numel(), rows, dim, _stream()),
-          "nrv_layernorm_bwd")
+    nb = rows * dim * (2 + x.element_size() + (dres.element_size() if dres is not None else 0)
+                       + (4 if want_f32 else 0) + (2 if want_bf16 else 0))
+    _run("layernorm_bwd", 0.0, nb,
+         lambda: lib.nrv_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _dt(x, "x"), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       _ptr(dres), _dt(dres, "dres") if dres is not None else 0,
+                                       _ptr(dx32), _ptr(dx16), dgamma.data_ptr(), dbeta.data_ptr(), int(bool(accumulate)),
+                                       ws.data_ptr(), ws.numel(), rows, dim, _stream()),
+         "nrv_layernorm_bwd")
     return dx32, dx16, dgamma, dbeta
 
 
@@ -124,12 +175,19 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
         _, _, ld_ao = _rows2d(aux_out, "aux_out")
     if bias is not None:
         _f32(bias, "bias")
-    check(_lib.load().nrv_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), _dt(out, "out"), ldc,
-                                       M, N, K, int(epilogue), _ptr(bias),
-                                       _ptr(aux), _dt(aux, "aux") if aux is not None else 0, ld_aux, int(aux_row_mod),
-                                       _ptr(aux_out), ld_ao, int(out_group), int(out_group_stride), int(out_row_offset),
-                                       _stream()),
-          "nrv_gemm_nt_bf16")
+    lib = _lib.load()
+    nb = 2 * (M * K + N * K) + M * N * out.element_size()
+    if aux is not None and not aux_row_mod:
+        nb += M * N * aux.element_size()
+    if aux_out is not None:
+        nb += M * N * 2
+    _run("gemm_nt", 2.0 * M * N * K, nb,
+         lambda: lib.nrv_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), _dt(out, "out"), ldc,
+                                      M, N, K, int(epilogue), _ptr(bias),
+                                      _ptr(aux), _dt(aux, "aux") if aux is not None else 0, ld_aux, int(aux_row_mod),
+                                      _ptr(aux_out), ld_ao, int(out_group), int(out_group_stride), int(out_row_offset),
+                                      _stream()),
+         "nrv_gemm_nt_bf16")
     return out
 
 
@@ -149,9 +207,10 @@ def gemm_tn(A: Tensor, B: Tensor, *, out: Optional[Tensor] = None, beta: float =
     _, _, ldc = _rows2d(out, "out")
     lib = _lib.load()
     ws = _workspace(lib.nrv_gemm_tn_workspace(M, N, T), A.device)
-    check(lib.nrv_gemm_tn_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, T, float(beta),
-                               int(a_group), int(a_group_stride), int(a_row_offset), ws.data_ptr(), ws.numel(), _stream()),
-          "nrv_gemm_tn_bf16")
+    _run("gemm_tn", 2.0 * M * N * T, 2 * T * (M + N) + 4 * M * N,
+         lambda: lib.nrv_gemm_tn_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, T, float(beta),
+                                      int(a_group), int(a_group_stride), int(a_row_offset), ws.data_ptr(), ws.numel(), _stream()),
+         "nrv_gemm_tn_bf16")
     return out
 
 
@@ -164,8 +223,9 @@ def colsum(X: Tensor, *, out: Optional[Tensor] = None, beta: float = 0.0) -> Ten
         beta = 0.0
     lib = _lib.load()
     ws = _workspace(lib.nrv_colsum_workspace(T, N), X.device)
-    check(lib.nrv_colsum_bf16(X.data_ptr(), ld, out.data_ptr(), T, N, float(beta), ws.data_ptr(), ws.numel(), _stream()),
-          "nrv_colsum_bf16")
+    _run("colsum", 0.0, 2 * T * N,
+         lambda: lib.nrv_colsum_bf16(X.data_ptr(), ld, out.data_ptr(), T, N, float(beta), ws.data_ptr(), ws.numel(), _stream()),
+         "nrv_colsum_bf16")
     return out
 
 
@@ -176,8 +236,10 @@ def attn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
         raise NrvError("attn_fwd: qkv must be contiguous [B*N, 3*H*dh]")
     out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
-    check(_lib.load().nrv_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, dh, float(scale), _stream()),
-          "nrv_attn_fwd")
+    lib = _lib.load()
+    _run("attn_fwd", 4.0 * B * H * N * N * dh, 2 * B * N * H * dh * 4,
+         lambda: lib.nrv_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, dh, float(scale), _stream()),
+         "nrv_attn_fwd")
     return out, lse
 
 
@@ -187,9 +249,11 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int
         raise NrvError("attn_bwd: operands must be contiguous")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B * H * N, dtype=torch.float32, device=qkv.device)
-    check(_lib.load().nrv_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                   delta.data_ptr(), B, N, H, dh, float(scale), _stream()),
-          "nrv_attn_bwd")
+    lib = _lib.load()
+    _run("attn_bwd", 10.0 * B * H * N * N * dh, 2 * B * N * H * dh * 8,
+         lambda: lib.nrv_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                  delta.data_ptr(), B, N, H, dh, float(scale), _stream()),
+         "nrv_attn_bwd")
     return dqkv
 
 
@@ -199,8 +263,10 @@ def patch_unfold(img: Tensor, p: int, layout: int) -> Tensor:
     img = img.contiguous()
     B, C, H, W = img.shape
     out = torch.empty(B * (H // p) * (W // p), C * p * p, dtype=torch.bfloat16, device=img.device)
-    check(_lib.load().nrv_patch_unfold(img.data_ptr(), _dt(img, "img"), out.data_ptr(), B, C, H, W, p, layout, _stream()),
-          "nrv_patch_unfold")
+    lib = _lib.load()
+    _run("patch_unfold", 0.0, img.numel() * (img.element_size() + 2),
+         lambda: lib.nrv_patch_unfold(img.data_ptr(), _dt(img, "img"), out.data_ptr(), B, C, H, W, p, layout, _stream()),
+         "nrv_patch_unfold")
     return out
 
 
@@ -211,7 +277,9 @@ def cast_transpose(w: Tensor, need_t: bool = True):
     R, C = w.shape
     wb = torch.empty(R, C, dtype=torch.bfloat16, device=w.device)
     wt = torch.empty(C, R, dtype=torch.bfloat16, device=w.device) if need_t else None
-    check(_lib.load().nrv_cast_transpose(w.data_ptr(), wb.data_ptr(), _ptr(wt), R, C, _stream()), "nrv_cast_transpose")
+    lib = _lib.load()
+    _run("cast_transpose", 0.0, R * C * 8,
+         lambda: lib.nrv_cast_transpose(w.data_ptr(), wb.data_ptr(), _ptr(wt), R, C, _stream()), "nrv_cast_transpose")
     return wb, wt
 
 
@@ -219,7 +287,9 @@ def cast_bf16(x: Tensor) -> Tensor:
     _f32(x, "x")
     x = x.contiguous()
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().nrv_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "nrv_cast_f32_bf16")
+    lib = _lib.load()
+    _run("cast_bf16", 0.0, x.numel() * 6,
+         lambda: lib.nrv_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "nrv_cast_f32_bf16")
     return y
 
 

@@ -1,0 +1,93 @@
+"""Training-step harness around the HIP encoder path (counterpart of the reference's examples/CIFAR100.py and
+examples/baseline.py, whose trainer base class `omega.Trainer` is not in the reference tree -- SURVEY.md §8a row a15).
+
+What the reference harness does per step and this module reproduces (file:line in /root/reference/examples/):
+  * even batch split across ranks                      CIFAR100.py:22, baseline.py:16
+  * loss = cross_entropy(model(x), y, label_smoothing=0.1)   CIFAR100.py:139, baseline.py:70
+  * optional noisy input  x + N(0, sigma^2)            nowak.py:152-159
+  * gradient clipping, max-norm 5.0                    CIFAR100.py:192, baseline.py:127
+  * AdamW(lr, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999))   CIFAR100.py:90-97,191
+  * per-iteration LinearLR(1e-3 -> 1) warm-up over 10 % of the epochs, then cosine to 0.05 lr   CIFAR100.py:99-113,165-166
+  * DDP: gradients averaged over ranks (all-reduce SUM / world) before the optimizer step
+
+The optimizer / clip / schedule arithmetic is PyTorch-ROCm's (`torch.optim.AdamW(fused=True)`): SURVEY.md §8f rank 3
+marks a hand-written fused optimizer as "next", not part of the encoder hot path.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def warmup_cosine_lr(step: int, base_lr: float, warmup_steps: int, cosine_steps: int,
+                     start_factor: float = 1e-3, eta_min_ratio: float = 0.05) -> float:
+    """Closed form of SequentialLR([LinearLR(start_factor, 1, T1), CosineAnnealingLR(T2, eta_min=0.05 lr)], [T1])
+    stepped once per iteration (CIFAR100.py:99-113).  Pinned against torch.optim.lr_scheduler in tests/test_train_host.py."""
+    if warmup_steps > 0 and step < warmup_steps:
+        return base_lr * (start_factor + (1.0 - start_factor) * step / warmup_steps)
+    t = step - warmup_steps
+    eta_min = base_lr * eta_min_ratio
+    if cosine_steps <= 0:
+        return base_lr
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * t / cosine_steps)) / 2.0
+
+
+@dataclass
+class TrainConfig:
+    lr: float = 5e-4
+    weight_decay: float = 0.05
+    grad_max_norm: float = 5.0
+    label_smoothing: float = 0.1
+    noise_std: float = 0.0
+    warmup_steps: int = 0
+    cosine_steps: int = 0
+
+
+class Trainer:
+    """One process per GPU.  `reducer` (parallel.GradReducer) is None for single-GPU runs."""
+
+    def __init__(self, model: torch.nn.Module, cfg: TrainConfig, reducer=None) -> None:
+        self.model, self.cfg, self.reducer = model, cfg, reducer
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.params = params
+        fused = all(p.is_cuda for p in params)
+        self.opt = torch.optim.AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay, eps=1e-8, betas=(0.9, 0.999),
+                                     fused=fused)
+        self.step_idx = 0
+
+    def loss_fn(self, logits: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        return F.cross_entropy(logits, y, label_smoothing=self.cfg.label_smoothing)
+
+    def forward_backward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        if self.cfg.noise_std > 0.0:
+            x = x + torch.randn_like(x) * self.cfg.noise_std          # nowak.py:153
+        if self.reducer is not None:
+            self.reducer.begin_step()
+        logits = self.model(x)
+        loss = self.loss_fn(logits, y)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish_step()          # waits for the overlapped all-reduces; grads are now rank-averaged
+        return loss.detach()
+
+    def optimizer_step(self) -> None:
+        c = self.cfg
+        if c.grad_max_norm and c.grad_max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.params, c.grad_max_norm, foreach=True)
+        if c.warmup_steps or c.cosine_steps:
+            lr = warmup_cosine_lr(self.step_idx, c.lr, c.warmup_steps, c.cosine_steps)
+            for g in self.opt.param_groups:
+                g["lr"] = lr
+        self.opt.step()
+        if self.reducer is None:
+            self.opt.zero_grad(set_to_none=True)
+        self.step_idx += 1
+
+    def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        loss = self.forward_backward(x, y)
+        self.optimizer_step()
+        return loss
