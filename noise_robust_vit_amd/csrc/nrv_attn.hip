@@ -22,7 +22,8 @@
 namespace {
 
 constexpr int DH = 64;
-constexpr int ATT_THREADS = 256;
+constexpr int ATT_THREADS = 512;      // 8 waves per (batch, head); 2 workgroups per CU -> 4 waves per SIMD
+constexpr int ATT_WAVES = ATT_THREADS / 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -95,7 +96,7 @@ __device__ __forceinline__ bf16x8_t row_frag_img(const char* img, int rb, int ks
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS, (NP <= 128 ? 4 : 2)) void attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;
     char* vimg = smem + NP * 128;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnParams 
     const int g = lane >> 4, qc = lane & 15;
     const float sc = p.scale * LOG2E;
     const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + qc;
         const int qr = q < N ? q : N - 1;
         bf16x8_t qf[2];
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnParams 
 // backward, query-owner pass: dQ and delta
 // ---------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_dq_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;
     char* vimg = smem + NP * 128;      // GEMM-swizzled row image here (row reads only)
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnPara
     const int g = lane >> 4, qc = lane & 15;
     const float sc = p.scale * LOG2E;
     const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + qc;
         const int qr = q < N ? q : N - 1;
         bf16x8_t qf[2], dof[2];
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnPara
         f32x4_t dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
         for (int kk = 0; kk < NP / 32; ++kk) {
             f32x4_t ds[2];
 #pragma unroll
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnPara
 // backward, key-owner pass: dK and dV
 // ---------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_dkv_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* qimg = smem;
     char* doimg = smem + NP * 128;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnPar
     const int g = lane >> 4, kc = lane & 15;
     const float sc = p.scale * LOG2E;
     const int nkt = (N + 15) >> 4;
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
         const int key = kt * 16 + kc;
         const int kr = key < N ? key : N - 1;
         bf16x8_t kf[2], vf[2];
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnPar
             dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             dv[dt] = dk[dt];
         }
-#pragma unroll
+#pragma unroll 1
         for (int qq = 0; qq < NP / 32; ++qq) {
             f32x4_t pt[2], ds[2];
 #pragma unroll

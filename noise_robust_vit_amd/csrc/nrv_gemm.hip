@@ -18,15 +18,36 @@
 //     every global access of the epilogue is a full 16-byte, row-contiguous access.
 //
 // Reference call sites replaced: simple_vit.py:39,41,61,62,130 ; vit.py:40-47 ; utils.py:115,579.
+#include <stdlib.h>
+
 #include "nrv_common.hpp"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BM = 256, BN = 256, BK = 64;   // TN kernel tile (and the NT "Cfg256" tile)
 constexpr int GEMM_THREADS = 512;
 constexpr int STAGE_BYTES = 65536;          // A tile 32 KiB + B tile 32 KiB
 constexpr int B_TILE_OFF = 32768;
 constexpr int GEMM_LDS_BYTES = 2 * STAGE_BYTES;
+
+// NT tile configurations: WM x WN waves, each wave MI x NI MFMA tiles of 16x16 (NI is 4 everywhere: the
+// epilogue transposes 16 x 64 slabs).
+//   Cfg256: 256x256 tile, 8 waves, 128 KiB LDS, one workgroup per CU  -- least L2 traffic per FLOP
+//   Cfg192: 192x128 tile, 4 waves,  80 KiB LDS, TWO workgroups per CU -- one workgroup's epilogue / prologue
+//           overlaps the other's MFMA main loop; the tile granularity also halves wave-quantisation loss
+template <int WM_, int WN_, int MI_, int NI_>
+struct TileCfg {
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
+    static constexpr int TBM = WM * MI * 16, TBN = WN * NI * 16;
+    static constexpr int NWAVES = WM * WN, THREADS = 64 * NWAVES;
+    static constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
+    static constexpr int CA = TBM * 8 / THREADS, CB = TBN * 8 / THREADS;     // DMA instructions per thread per tile
+    static constexpr int LDS = 2 * STAGE;
+    static_assert(NI == 4, "epilogue slab is 64 columns");
+    static_assert(TBM * 8 % THREADS == 0 && TBN * 8 % THREADS == 0, "whole DMA instructions");
+};
+using Cfg256 = TileCfg<2, 4, 8, 4>;
+using Cfg192 = TileCfg<2, 2, 6, 4>;
 constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
 constexpr int EPI_PATCH_BYTES = 16 * EPI_ROW_F32 * 4;   // 4352 B per wave
 
@@ -47,6 +68,8 @@ struct GemmNTParams {
     long long lda, ldb;
     int K;
     int tiles_n;
+    int stagger;
+    unsigned long long* stamps;   // debug only (NRV_GEMM_STAMPS=1): 4 x s_memrealtime + hw id per workgroup
     EpiParams e;
 };
 
@@ -73,8 +96,8 @@ __device__ __forceinline__ int remap_row(int m, int group, int group_stride, int
 // Epilogue shared by both kernels.  acc[mi][ni] holds, for lane l: row  m = 16 mi + (l & 15),
 // columns n = 16 ni + 4 (l >> 4) + {0,1,2,3} of the wave's 128 x 64 block.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, bool OUT_F32, bool AUX_F32>
-__device__ __forceinline__ void epilogue(f32x4_t (&acc)[8][4], char* smem, const EpiParams& e,
+template <int EPI, bool OUT_F32, bool AUX_F32, int MI>
+__device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, const EpiParams& e,
                                          int row_base /* global row of the wave's block */,
                                          int col_base /* global col of the wave's block */,
                                          int lane, int wave) {
@@ -83,6 +106,9 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[8][4], char* smem, const
     const int rcol4 = lane & 15, rrow = lane >> 4;      // read side: float4 column, row phase
     const int ncol = col_base + rcol4 * 4;
     const bool col_ok = ncol < e.N;
+    constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
+    constexpr bool AUX32 = EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32;
+    constexpr int HALF = (MI + 1) / 2;
 
     f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
     if (EPI == NRV_EPI_BIAS || EPI == NRV_EPI_BIAS_GELU || EPI == NRV_EPI_BIAS_RESIDUAL) {
@@ -90,46 +116,76 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[8][4], char* smem, const
     }
 
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
+    for (int h0 = 0; h0 < MI; h0 += HALF) {
+        // Epilogue operands (residual stream / saved pre-activation) do not depend on the LDS transposition:
+        // issue the loads of half the wave's block up front so that 4 x HALF requests per lane are in flight
+        // (one dependent load per slab made this phase latency-bound: 27 us per 256x256 fp32-residual tile).
+        f32x4_t aux32[AUX32 ? HALF : 1][4];
+        u32x2_t aux16[(HAS_AUX && !AUX32) ? HALF : 1][4];
+        if (HAS_AUX) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            *reinterpret_cast<f32x4_t*>(stg + wc_row * EPI_ROW_F32 + ni * 16 + wg * 4) = acc[mi][ni];
+            for (int mh = 0; mh < HALF; ++mh) {
+                const int mi = h0 + mh;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rrow + 4 * i;
-            f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + r * EPI_ROW_F32 + rcol4 * 4);
-            const int m = row_base + mi * 16 + r;
-            if (m < e.M && col_ok) {
-                v += bias4;
-                const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
-                if (EPI == NRV_EPI_BIAS_GELU) {
-                    if (e.aux_out != nullptr) {
-                        u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.aux_out) + orow * e.ld_aux_out + ncol) = pk;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_fwd(v[j]);
-                }
-                if (EPI == NRV_EPI_BIAS_RESIDUAL) {
-                    const long long arow = e.aux_row_mod > 0 ? (long long)(m % e.aux_row_mod) : orow;
-                    if (AUX_F32) {
-                        v += *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.aux) + arow * e.ld_aux + ncol);
+                for (int i = 0; i < 4; ++i) {
+                    const int m = row_base + mi * 16 + rrow + 4 * i;
+                    const bool ok = mi < MI && m < e.M && col_ok;
+                    const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
+                    const long long arow = (EPI == NRV_EPI_BIAS_RESIDUAL && e.aux_row_mod > 0) ? (long long)(m % e.aux_row_mod) : orow;
+                    if (AUX32) {
+                        aux32[mh][i] = ok ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.aux) + arow * e.ld_aux + ncol)
+                                          : f32x4_t{0.f, 0.f, 0.f, 0.f};
                     } else {
-                        const u32x2_t a = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + arow * e.ld_aux + ncol);
-                        v[0] += bf16lo_to_f32(a[0]); v[1] += bf16hi_to_f32(a[0]);
-                        v[2] += bf16lo_to_f32(a[1]); v[3] += bf16hi_to_f32(a[1]);
+                        aux16[mh][i] = ok ? *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + arow * e.ld_aux + ncol)
+                                          : u32x2_t{0u, 0u};
                     }
                 }
-                if (EPI == NRV_EPI_DGELU) {
-                    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + orow * e.ld_aux + ncol);
-                    v[0] *= gelu_grad(bf16lo_to_f32(a[0])); v[1] *= gelu_grad(bf16hi_to_f32(a[0]));
-                    v[2] *= gelu_grad(bf16lo_to_f32(a[1])); v[3] *= gelu_grad(bf16hi_to_f32(a[1]));
-                }
-                if (OUT_F32) {
-                    *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.C) + orow * e.ldc + ncol) = v;
-                } else {
-                    u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.C) + orow * e.ldc + ncol) = pk;
+            }
+        }
+#pragma unroll
+        for (int mh = 0; mh < HALF; ++mh) {
+            const int mi = h0 + mh;
+            if (mi < MI) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    *reinterpret_cast<f32x4_t*>(stg + wc_row * EPI_ROW_F32 + ni * 16 + wg * 4) = acc[mi][ni];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rrow + 4 * i;
+                    f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + r * EPI_ROW_F32 + rcol4 * 4);
+                    const int m = row_base + mi * 16 + r;
+                    if (m < e.M && col_ok) {
+                        v += bias4;
+                        const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
+                        if (EPI == NRV_EPI_BIAS_GELU) {
+                            if (e.aux_out != nullptr) {
+                                u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                                *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.aux_out) + orow * e.ld_aux_out + ncol) = pk;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = gelu_fwd(v[j]);
+                        }
+                        if (EPI == NRV_EPI_BIAS_RESIDUAL) {
+                            if (AUX32) {
+                                v += aux32[mh][i];
+                            } else {
+                                const u32x2_t a = aux16[mh][i];
+                                v[0] += bf16lo_to_f32(a[0]); v[1] += bf16hi_to_f32(a[0]);
+                                v[2] += bf16lo_to_f32(a[1]); v[3] += bf16hi_to_f32(a[1]);
+                            }
+                        }
+                        if (EPI == NRV_EPI_DGELU) {
+                            const u32x2_t a = aux16[mh][i];
+                            v[0] *= gelu_grad(bf16lo_to_f32(a[0])); v[1] *= gelu_grad(bf16hi_to_f32(a[0]));
+                            v[2] *= gelu_grad(bf16lo_to_f32(a[1])); v[3] *= gelu_grad(bf16hi_to_f32(a[1]));
+                        }
+                        if (OUT_F32) {
+                            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.C) + orow * e.ldc + ncol) = v;
+                        } else {
+                            u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.C) + orow * e.ldc + ncol) = pk;
+                        }
+                    }
                 }
             }
         }
@@ -141,82 +197,117 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[8][4], char* smem, const
 // stored at chunk position c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for the MFMA fragment
 // pattern (lane & 15 = row, lane >> 4 = chunk).
 // ---------------------------------------------------------------------------------------------
-template <int EPI, bool OUT_F32, bool AUX_F32>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmNTParams p) {
+template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
+__global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / C::WN, wc = wave - wr * C::WN;
 
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * C::TBM, n0 = tn * C::TBN;
     const int M = p.e.M, N = p.e.N, K = p.K;
 
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
 
-    // staging: DMA instruction i of this wave fills rows 8*(8 i + wave) .. +7 of a tile
-    unsigned st_a[4], st_b[4], st_c[4];
+    // staging: DMA instruction i of this wave fills rows 8*(NWAVES i + wave) .. +7 of a tile
+    unsigned st_a[C::CA], st_b[C::CB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+    for (int i = 0; i < C::CA; ++i) {
+        const int r = (i * C::NWAVES + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        st_a[i] = (unsigned)((long long)r * p.lda * 2) + c * 16;
-        st_b[i] = (unsigned)((long long)r * p.ldb * 2) + c * 16;
-        st_c[i] = c * 8;                                   // k offset of the chunk inside the K-tile
-        // rows past M / N: the byte offset is >= num_records by construction (records = rows_left*ld*2)
-        if (m0 + r >= M) st_a[i] = NRV_OOB;
-        if (n0 + r >= N) st_b[i] = NRV_OOB;
+        st_a[i] = (m0 + r < M) ? (unsigned)((long long)r * p.lda * 2) + c * 16 : NRV_OOB;
     }
-
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE_BYTES;
-        const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool kok = (k0 + (int)st_c[i]) < K;
-            const unsigned va = (kok && st_a[i] != NRV_OOB) ? st_a[i] + k0 * 2 : NRV_OOB;
-            const unsigned vb = (kok && st_b[i] != NRV_OOB) ? st_b[i] + k0 * 2 : NRV_OOB;
-            dma16(ra, base + (i * 8 + wave) * 1024, va);
-            dma16(rb, base + B_TILE_OFF + (i * 8 + wave) * 1024, vb);
-        }
+    for (int i = 0; i < C::CB; ++i) {
+        const int r = (i * C::NWAVES + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        st_b[i] = (n0 + r < N) ? (unsigned)((long long)r * p.ldb * 2) + c * 16 : NRV_OOB;
+    }
+    // one DMA instruction (index d of the CA + CB that make up a K-tile) of tile kt into stage buffer buf
+    auto dma_one = [&](int buf, int kt, int d) {
+        char* base = smem + buf * C::STAGE;
+        const int k0 = kt * BK;
+        const bool isA = d < C::CA;
+        const int i = isA ? d : d - C::CA;
+        const int r = (i * C::NWAVES + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const unsigned so = isA ? st_a[isA ? i : 0] : st_b[isA ? 0 : i];
+        const bool ok = (k0 + c * 8 < K) && so != NRV_OOB;
+        dma16(isA ? ra : rb, base + (isA ? 0 : C::A_BYTES) + (i * C::NWAVES + wave) * 1024, ok ? so + k0 * 2 : NRV_OOB);
     };
+    constexpr int ND = C::CA + C::CB;            // DMA instructions per thread per K-tile
+    constexpr int NG = C::MI;                    // MFMA groups per K-tile: 2 k-steps x MI/2 row pairs
 
     // fragment read offsets
     const int fr = lane & 15, fg = lane >> 4;
     const int swz = (fg ^ ((fr >> 1) & 7)) << 4;
-    const int a_rd = (wr * 128 + fr) * 128 + swz;
-    const int b_rd = B_TILE_OFF + (wc * 64 + fr) * 128 + swz;
+    const int a_rd = (wr * (C::MI * 16) + fr) * 128 + swz;
+    const int b_rd = C::A_BYTES + (wc * (C::NI * 16) + fr) * 128 + swz;
 
-    f32x4_t acc[8][4];
+    f32x4_t acc[C::MI][C::NI];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (K + BK - 1) / BK;
-    stage(0, 0);
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (p.stamps) t0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dma_one(0, 0, d);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sa = smem + cur * STAGE_BYTES;
+        if (p.stamps && kt == 0) t1 = __builtin_amdgcn_s_memrealtime();
+        const bool more = kt + 1 < nk;
+        const char* sa = smem + cur * C::STAGE;
+        // The next tile's DMA instructions are spread over the MFMA groups of this tile (each costs the issuing
+        // wave tens to >100 cycles): issued in one burst after the barrier they stall both waves of every SIMD.
+        // fragment reads run one MFMA group ahead of their use (register double buffering)
+        constexpr int GH = C::MI / 2;                 // groups per k-step
+        bf16x8_t bfr[2][C::NI], af[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[8], bfr[4];
+        for (int ni = 0; ni < C::NI; ++ni) bfr[0][ni] = lds_read_b128(sa + (b_rd + ni * 2048));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bfr[ni] = lds_read_b128(sa + ((b_rd ^ (ks << 6)) + ni * 2048));
+        for (int j = 0; j < 2; ++j) af[0][j] = lds_read_b128(sa + (a_rd + j * 2048));
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) af[mi] = lds_read_b128(sa + ((a_rd ^ (ks << 6)) + mi * 2048));
+        for (int g = 0; g < NG; ++g) {
+            const int ks = g / GH, mp = g % GH;
+            if (g + 1 < NG) {
+                const int ks1 = (g + 1) / GH, mp1 = (g + 1) % GH;
+                if (mp1 == 0) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+                    for (int ni = 0; ni < C::NI; ++ni) bfr[ks1 & 1][ni] = lds_read_b128(sa + ((b_rd ^ (ks1 << 6)) + ni * 2048));
+                }
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bfr[ni], af[mi], acc[mi][ni]);
+                for (int j = 0; j < 2; ++j) af[(g + 1) & 1][j] = lds_read_b128(sa + ((a_rd ^ (ks1 << 6)) + (2 * mp1 + j) * 2048));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ni = 0; ni < C::NI; ++ni)
+                    acc[2 * mp + j][ni] = mfma16(bfr[ks & 1][ni], af[g & 1][j], acc[2 * mp + j][ni]);
+            if (more) {
+#pragma unroll
+                for (int d = g * ND / NG; d < (g + 1) * ND / NG; ++d) dma_one(cur ^ 1, kt + 1, d);
+            }
         }
     }
     __syncthreads();     // every wave is done with the tile buffers: reuse them as epilogue patches
-    epilogue<EPI, OUT_F32, AUX_F32>(acc, smem, p.e, m0 + wr * 128, n0 + wc * 64, lane, wave);
+    if (p.stamps) t2 = __builtin_amdgcn_s_memrealtime();
+    epilogue<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* o = p.stamps + (unsigned long long)blockIdx.x * 5;
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_memrealtime();
+            o[4] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4 /* HW_REG_HW_ID */) | ((unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20 /* XCC_ID */) << 32);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,7 +406,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     __syncthreads();
     EpiParams e = p.e;
     e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
-    epilogue<NRV_EPI_NONE, true, true>(acc, smem, e, m0 + wr * 128, n0 + wc * 64, lane, wave);
+    epilogue<NRV_EPI_NONE, true, true, 8>(acc, smem, e, m0 + wr * 128, n0 + wc * 64, lane, wave);
 }
 
 // C = beta * C + sum_s slab[s]
@@ -335,18 +426,49 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long long 
     }
 }
 
+// debug: per-workgroup phase stamps (NRV_GEMM_STAMPS=1).  Never enabled in measured or shipped runs.
+constexpr size_t STAMP_BYTES = 8u << 20;
+unsigned long long* debug_stamp_buffer() {
+    static unsigned long long* buf = [] {
+        const char* e = getenv("NRV_GEMM_STAMPS");
+        void* p = nullptr;
+        if (e && atoi(e) && hipMalloc(&p, STAMP_BYTES) != hipSuccess) p = nullptr;
+        return static_cast<unsigned long long*>(p);
+    }();
+    return buf;
+}
+
 template <typename KernelT>
-int set_lds(KernelT k) {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+int set_lds(KernelT k, int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
+int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
+    static int attr = set_lds(gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32>, C::LDS);
+    if (attr != 0) return attr;
+    const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
+    p.tiles_n = tiles_n;
+    static const int stagger = [] { const char* e = getenv("NRV_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = stagger;
+    p.stamps = debug_stamp_buffer();
+    hipLaunchKernelGGL((gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
+// tile selection: NRV_GEMM_TILE=256|192 forces a configuration (bench / tests); default = heuristic
+int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
+    static const int forced = [] { const char* e = getenv("NRV_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 256 || forced == 192) return forced;
+    (void)M; (void)N; (void)K;
+    return 256;      // measured on the ViT-B/16 shapes: Cfg192 is LDS-DMA-bandwidth bound (2 x 40 KiB per K-step per CU)
 }
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
-int launch_nt(const GemmNTParams& p, int grid, hipStream_t s) {
-    static int attr = set_lds(gemm_nt_kernel<EPI, OUT_F32, AUX_F32>);
-    if (attr != 0) return attr;
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OUT_F32, AUX_F32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, p);
-    NRV_CHECK_LAUNCH();
-    return 0;
+int launch_nt(const GemmNTParams& p, hipStream_t s) {
+    if (nt_tile_choice(p.e.M, p.e.N, p.K) == 256) return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
+    return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32>(p, s);
 }
 
 int tn_splits(int64_t M, int64_t N, int64_t T) {
@@ -394,32 +516,36 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     p.A = static_cast<const bf16_t*>(A);
     p.B = static_cast<const bf16_t*>(B);
     p.lda = lda; p.ldb = ldb; p.K = (int)K;
-    const int tiles_m = (int)nrv_cdiv(M, BM), tiles_n = (int)nrv_cdiv(N, BN);
-    p.tiles_n = tiles_n;
+    p.tiles_n = 0;
     p.e.C = C; p.e.bias = bias; p.e.aux = aux; p.e.aux_out = aux_out;
     p.e.ldc = ldc; p.e.ld_aux = ld_aux; p.e.ld_aux_out = ld_aux_out;
     p.e.M = (int)M; p.e.N = (int)N;
     p.e.aux_row_mod = (int)aux_row_mod;
     p.e.out_group = (int)out_group; p.e.out_group_stride = (int)out_group_stride; p.e.out_row_offset = (int)out_row_offset;
-    const int grid = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool of32 = c_dtype == NRV_F32;
     const bool af32 = aux_dtype == NRV_F32;
     switch (epilogue_id) {
         case NRV_EPI_NONE:
-            return of32 ? launch_nt<NRV_EPI_NONE, true, true>(p, grid, s) : launch_nt<NRV_EPI_NONE, false, true>(p, grid, s);
+            return of32 ? launch_nt<NRV_EPI_NONE, true, true>(p, s) : launch_nt<NRV_EPI_NONE, false, true>(p, s);
         case NRV_EPI_BIAS:
-            return of32 ? launch_nt<NRV_EPI_BIAS, true, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS, false, true>(p, grid, s);
+            return of32 ? launch_nt<NRV_EPI_BIAS, true, true>(p, s) : launch_nt<NRV_EPI_BIAS, false, true>(p, s);
         case NRV_EPI_BIAS_GELU:
-            return of32 ? launch_nt<NRV_EPI_BIAS_GELU, true, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS_GELU, false, true>(p, grid, s);
+            return of32 ? launch_nt<NRV_EPI_BIAS_GELU, true, true>(p, s) : launch_nt<NRV_EPI_BIAS_GELU, false, true>(p, s);
         case NRV_EPI_BIAS_RESIDUAL:
-            if (of32) return af32 ? launch_nt<NRV_EPI_BIAS_RESIDUAL, true, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS_RESIDUAL, true, false>(p, grid, s);
-            return af32 ? launch_nt<NRV_EPI_BIAS_RESIDUAL, false, true>(p, grid, s) : launch_nt<NRV_EPI_BIAS_RESIDUAL, false, false>(p, grid, s);
+            if (of32) return af32 ? launch_nt<NRV_EPI_BIAS_RESIDUAL, true, true>(p, s) : launch_nt<NRV_EPI_BIAS_RESIDUAL, true, false>(p, s);
+            return af32 ? launch_nt<NRV_EPI_BIAS_RESIDUAL, false, true>(p, s) : launch_nt<NRV_EPI_BIAS_RESIDUAL, false, false>(p, s);
         case NRV_EPI_DGELU:
-            return of32 ? launch_nt<NRV_EPI_DGELU, true, false>(p, grid, s) : launch_nt<NRV_EPI_DGELU, false, false>(p, grid, s);
+            return of32 ? launch_nt<NRV_EPI_DGELU, true, false>(p, s) : launch_nt<NRV_EPI_DGELU, false, false>(p, s);
         default:
             return NRV_ERR_EPILOGUE;
     }
+}
+
+extern "C" int nrv_debug_read_stamps(unsigned long long* host_out, size_t count) {
+    unsigned long long* b = debug_stamp_buffer();
+    if (!b || !host_out || count * 8 > STAMP_BYTES) return NRV_ERR_NULL;
+    return (int)hipMemcpy(host_out, b, count * 8, hipMemcpyDeviceToHost);
 }
 
 extern "C" size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T) {
@@ -466,7 +592,7 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     else { p.e.C = workspace; p.e.ldc = N; p.slab_stride = (long long)M * N; }
 
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static int attr = set_lds(gemm_tn_kernel);
+    static int attr = set_lds(gemm_tn_kernel, GEMM_LDS_BYTES);
     if (attr != 0) return attr;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, p);
     NRV_CHECK_LAUNCH();
