@@ -12,7 +12,8 @@ import threading
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnrv_hip.so")
+# NRV_LIB_PATH: developer override used to A/B kernel variants (tools/); the shipped path is the in-tree library
+LIB_PATH = os.environ.get("NRV_LIB_PATH") or os.path.join(_HERE, "lib", "libnrv_hip.so")
 
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4

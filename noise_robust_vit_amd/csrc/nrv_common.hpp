@@ -87,8 +87,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 }
 
 // 16-byte LDS-DMA: lane l's 16 bytes land at lds_base + 16*l (lds_base wave-uniform).
+// Issued through inline asm so that hipcc's waitcnt pass does not know an LDS-DMA is in flight: with the builtin
+// it drains vmcnt(0) in front of every later ds_read_b64_tr_b16 (seen in the TN kernel's .s), which serialises
+// load and compute.  The kernels wait for these loads themselves (s_waitcnt vmcnt(0) + barrier before the reads).
+// M0 (the LDS base of the DMA) is compiler-reserved: save / set / restore it inside the one statement.
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_base), 16, voffset, 0, 0, 0);
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_base));
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc), "s"(lds_addr)
+        : "memory");
 }
 
 __device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {

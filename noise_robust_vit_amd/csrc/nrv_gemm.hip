@@ -22,6 +22,10 @@
 
 #include "nrv_common.hpp"
 
+#ifndef NRV_DMA_GROUPS
+#define NRV_DMA_GROUPS 4
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;   // TN kernel tile (and the NT "Cfg256" tile)
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
     };
     constexpr int ND = C::CA + C::CB;            // DMA instructions per thread per K-tile
     constexpr int NG = C::MI;                    // MFMA groups per K-tile: 2 k-steps x MI/2 row pairs
+    constexpr int NGD = NRV_DMA_GROUPS < NG ? NRV_DMA_GROUPS : NG;   // groups that carry the next tile's DMA issue
 
     // fragment read offsets
     const int fr = lane & 15, fg = lane >> 4;
@@ -290,9 +295,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 #pragma unroll
                 for (int ni = 0; ni < C::NI; ++ni)
                     acc[2 * mp + j][ni] = mfma16(bfr[ks & 1][ni], af[g & 1][j], acc[2 * mp + j][ni]);
-            if (more) {
+            if (more && g < NGD) {
 #pragma unroll
-                for (int d = g * ND / NG; d < (g + 1) * ND / NG; ++d) dma_one(cur ^ 1, kt + 1, d);
+                for (int d = g * ND / NGD; d < (g + 1) * ND / NGD; ++d) dma_one(cur ^ 1, kt + 1, d);
             }
         }
     }
@@ -350,16 +355,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
         st_col[i] = (ul * 2 + (ch & 1)) * 8;
     }
 
-    auto stage = [&](int buf, int kt) {
+    // one DMA instruction d (0..3: A rows, 4..7: B rows) of K-tile kt into stage buffer buf
+    auto dma_one = [&](int buf, int kt, int d) {
         char* base = smem + buf * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = t_begin + kt * BK + st_r[i];
-            const bool tok = t < t_end;
+        const bool isA = d < 4;
+        const int i = d & 3;
+        const int t = t_begin + kt * BK + st_r[i];
+        const bool tok = t < t_end;
+        if (isA) {
             const long long ar = remap_row(t, p.a_group, p.a_group_stride, p.a_row_offset) - arow0;
             const unsigned va = (tok && (m0 + st_col[i] < M)) ? (unsigned)((ar * p.lda + st_col[i]) * 2) : NRV_OOB;
-            const unsigned vb = (tok && (n0 + st_col[i] < N)) ? (unsigned)(((long long)(t - t_begin) * p.ldb + st_col[i]) * 2) : NRV_OOB;
             dma16(ra, base + (i * 8 + wave) * 1024, va);
+        } else {
+            const unsigned vb = (tok && (n0 + st_col[i] < N)) ? (unsigned)(((long long)(t - t_begin) * p.ldb + st_col[i]) * 2) : NRV_OOB;
             dma16(rb, base + B_TILE_OFF + (i * 8 + wave) * 1024, vb);
         }
     };
@@ -377,30 +385,53 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) stage(0, 0);
+    auto ld_a = [&](const char* sa, int ks, int mi) {
+        const char* q = sa + ((a_tr ^ (mi << 5)) + ks * (32 * 512));
+        return cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+    };
+    auto ld_b = [&](const char* sa, int ks, int ni) {
+        const char* q = sa + ((b_tr ^ (ni << 5)) + ks * (32 * 512));
+        return cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+    };
+
+    if (nk > 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dma_one(0, 0, d);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const bool more = kt + 1 < nk;
         const char* sa = smem + cur * STAGE_BYTES;
+        // same schedule as the NT kernel: fragment reads one MFMA group ahead, next tile's DMA issue spread over
+        // the first half of the groups
+        bf16x8_t bfr[2][4], af[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[8], bfr[4];
+        for (int ni = 0; ni < 4; ++ni) bfr[0][ni] = ld_b(sa, 0, ni);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const char* q = sa + ((b_tr ^ (ni << 5)) + ks * (32 * 512));
-                bfr[ni] = cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+        for (int j = 0; j < 2; ++j) af[0][j] = ld_a(sa, 0, j);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int ks = g >> 2, mp = g & 3;
+            if (g + 1 < 8) {
+                const int ks1 = (g + 1) >> 2, mp1 = (g + 1) & 3;
+                if (mp1 == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) bfr[ks1 & 1][ni] = ld_b(sa, ks1, ni);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) af[(g + 1) & 1][j] = ld_a(sa, ks1, 2 * mp1 + j);
             }
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const char* q = sa + ((a_tr ^ (mi << 5)) + ks * (32 * 512));
-                af[mi] = cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[2 * mp + j][ni] = mfma16(bfr[ks & 1][ni], af[g & 1][j], acc[2 * mp + j][ni]);
+            if (more && g < 4) {
+                dma_one(cur ^ 1, kt + 1, 2 * g);
+                dma_one(cur ^ 1, kt + 1, 2 * g + 1);
             }
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bfr[ni], af[mi], acc[mi][ni]);
         }
     }
     __syncthreads();

@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library builds for gfx950, loads without a GPU, and exports exactly what include/nrv.h declares
+(no compute calls here).  Also: argument errors are reported by return code before any launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from noise_robust_vit_amd import build
+    return build.build()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nrv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nrv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_binding_and_library_agree(lib_path):
+    from noise_robust_vit_amd import _lib
+    hdr = header_symbols()
+    assert hdr == sorted(_lib.SIGNATURES), (set(hdr) ^ set(_lib.SIGNATURES))
+    handle = ctypes.CDLL(lib_path)
+    for name in hdr:
+        assert hasattr(handle, name), f"{name} declared in nrv.h but not exported"
+    assert handle.nrv_abi_version() == _lib.ABI_VERSION
+
+
+def test_loader_sets_prototypes_and_reports_errors(lib_path):
+    from noise_robust_vit_amd import _lib
+    lib = _lib.load()
+    assert lib.nrv_error_string(0) == b"ok"
+    # host-side argument validation happens before any launch: callable without a GPU
+    assert lib.nrv_gemm_nt_bf16(None, 8, None, 8, None, 1, 8, 8, 8, 8, 0, None, None, 0, 0, 0, None, 0, 0, 0, 0, None) == -1
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 300, 1, 64, ctypes.c_float(0.125), None) == -2          # N > 256
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 10, 1, 80, ctypes.c_float(0.125), None) == -2           # dh != 64
+    assert lib.nrv_layernorm_fwd(16, 0, 16, 16, 16, 16, 16, 4, 12, ctypes.c_float(1e-5), None) == -2   # dim % 8
+    assert b"shape" in lib.nrv_error_string(-2)
+    with pytest.raises(_lib.NrvError):
+        _lib.check(-4, "demo")
+    assert lib.nrv_gemm_tn_workspace(3072, 768, 50432) == 7 * 3072 * 768 * 4                    # 36 tiles -> 7 splits
+    assert lib.nrv_layernorm_bwd_workspace(50432, 768) == 512 * 2 * 768 * 4
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from noise_robust_vit_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.NrvError, match="no fallback"):
+        _lib.load()

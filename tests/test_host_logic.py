@@ -1,0 +1,136 @@
+"""CPU: host-side logic of the drop-in modules -- constructor signatures, state_dict contract, initialisers,
+checkpoint interop, LR schedule -- and the rule that the product never touches the oracle or a CPU fallback."""
+import ast
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_simplevit_state_dict_and_seeded_init_equal_the_reference(golden_dir):
+    """Same module construction order as simple_vit.py => same RNG consumption => identical weights under a seed."""
+    from noise_robust_vit_amd import SimpleViT
+    g = np.load(f"{golden_dir}/simplevit_cfg1_weights.npz")
+    torch.manual_seed(0)
+    m = SimpleViT(image_size=32, patch_size=16, num_classes=100, dim=192, depth=2, heads=3, mlp_dim=768)
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(g.keys())
+    for k in g.keys():
+        assert np.array_equal(sd[k].numpy(), g[k]), k
+    m2 = SimpleViT(image_size=32, patch_size=16, num_classes=100, dim=192, depth=2, heads=3, mlp_dim=768, robust=True)
+    assert sorted(m2.state_dict()) == sorted(sd)                        # SinkhornAttention has no parameters
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in g.items()})
+
+
+def test_vision_transformer_keys_shapes_and_init():
+    from noise_robust_vit_amd.vit import VisionTransformer, vit_b_16
+    from oracle import vit_oracle as V
+    cfg = dict(image_size=32, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10)
+    m = VisionTransformer(**cfg)
+    ref = V.vit_init_state_dict(seed=0, **cfg)
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(ref)                                     # SURVEY.md §8b key contract
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    assert sd["heads.head.weight"].abs().max() == 0 and sd["class_token"].abs().max() == 0     # vit.py:247,304-306
+    blk = "encoder.layers.encoder_layer_0."
+    assert sd[blk + "self_attention.in_proj_bias"].abs().max() == 0                              # utils.py:727
+    assert sd[blk + "mlp.0.bias"].abs().max() < 1e-4                                             # vit.py:53
+    assert abs(sd["encoder.pos_embedding"].std().item() - 0.02) < 0.003
+    b = vit_b_16()
+    assert sum(p.numel() for p in b.parameters()) == 86567656           # torchvision vit_b_16 parameter count
+    m.load_state_dict(ref)
+
+
+def test_legacy_mlp_keys_load():
+    from noise_robust_vit_amd.vit import VisionTransformer
+    m = VisionTransformer(image_size=32, patch_size=16, num_layers=1, num_heads=1, hidden_dim=64, mlp_dim=128, num_classes=3)
+    legacy = {k.replace(".mlp.0.", ".mlp.linear_1.").replace(".mlp.3.", ".mlp.linear_2."): v.clone() + 1.0
+              for k, v in m.state_dict().items()}
+    m.load_state_dict(legacy)                                            # vit.py:55-84
+    assert torch.equal(m.encoder.layers.encoder_layer_0.mlp[3].bias.data,
+                       legacy["encoder.layers.encoder_layer_0.mlp.linear_2.bias"])
+
+
+def test_cpu_forward_fails_loudly_no_fallback():
+    from noise_robust_vit_amd import Attention, SimpleViT
+    from noise_robust_vit_amd._lib import NrvError
+    m = SimpleViT(image_size=32, patch_size=16, num_classes=10, dim=64, depth=1, heads=1, mlp_dim=128)
+    with pytest.raises(NrvError, match="no CPU fallback"):
+        m(torch.randn(2, 3, 32, 32))
+    with pytest.raises(NrvError):
+        Attention(64, heads=1)(torch.randn(2, 4, 64))
+
+
+def test_sincos_table_matches_oracle():
+    from noise_robust_vit_amd.simple_vit import sincos_table_2d
+    from oracle.simple_vit_oracle import posemb_sincos_2d
+    for h, w, d in ((2, 2, 192), (14, 14, 768), (3, 5, 64)):
+        assert (sincos_table_2d(h, w, d) - posemb_sincos_2d(h, w, d)).abs().max() < 1e-6
+
+
+def test_warmup_cosine_lr_matches_torch_schedulers():
+    """Closed form vs SequentialLR([LinearLR(1e-3,1,T1), CosineAnnealingLR(T2, eta_min=0.05 lr)]) (CIFAR100.py:99-113)."""
+    from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
+    from noise_robust_vit_amd.train import warmup_cosine_lr
+    base, T1, T2 = 5e-4, 7, 31
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=base)
+    sched = SequentialLR(opt, [LinearLR(opt, 1e-3, 1, total_iters=T1), CosineAnnealingLR(opt, T_max=T2, eta_min=base * 0.05)],
+                         milestones=[T1])
+    for step in range(T1 + T2):
+        assert math.isclose(opt.param_groups[0]["lr"], warmup_cosine_lr(step, base, T1, T2), rel_tol=1e-6, abs_tol=1e-12), step
+        opt.step(); sched.step()
+
+
+def _imports(path):
+    tree = ast.parse(open(path).read())
+    out = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            out |= {a.name.split(".")[0] for a in node.names}
+        elif isinstance(node, ast.ImportFrom) and node.module and node.level == 0:
+            out.add(node.module.split(".")[0])
+    return out
+
+
+def _non_doc_strings_with(path, needle):
+    tree = ast.parse(open(path).read())
+    docs = set()
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.Module, ast.ClassDef, ast.FunctionDef)) and node.body and \
+                isinstance(node.body[0], ast.Expr) and isinstance(node.body[0].value, ast.Constant):
+            docs.add(id(node.body[0].value))
+    return [n.value for n in ast.walk(tree)
+            if isinstance(n, ast.Constant) and isinstance(n.value, str) and needle in n.value and id(n) not in docs]
+
+
+def test_product_never_imports_the_oracle_or_reads_the_reference():
+    pkg = os.path.join(ROOT, "noise_robust_vit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                path = os.path.join(dirpath, f)
+                assert "oracle" not in _imports(path), path
+                assert not _non_doc_strings_with(path, "/root/reference"), path     # citations in docstrings are fine
+    # bench.py may use the oracle only inside cpu_baseline(); smoke() only as a checker
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name != "cpu_baseline":
+            for sub in ast.walk(node):
+                if isinstance(sub, ast.ImportFrom) and sub.module and sub.module.startswith("oracle"):
+                    raise AssertionError(f"bench.py:{node.name} imports the oracle")
+
+
+def test_robust_flag_is_plumbed_not_substituted():
+    """robust=True must never silently run softmax attention."""
+    from noise_robust_vit_amd import SimpleViT
+    from noise_robust_vit_amd.simple_vit import SinkhornAttention
+    m = SimpleViT(image_size=32, patch_size=16, num_classes=10, dim=64, depth=1, heads=1, mlp_dim=128, robust=True)
+    assert isinstance(m.transformer.layers[0][0].attend, SinkhornAttention)
+    assert m.transformer._meta.robust and m.transformer.layers[0][0]._meta.robust
