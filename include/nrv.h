@@ -139,6 +139,18 @@ int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const void* dout_bf
                  void* dqkv_bf16, float* delta_ws,
                  int B, int N, int H, int dh, float scale, void* stream);
 
+/* "robust" attention (robust=True): softmax followed by Sinkhorn normalisation -- 3 x (row /, column /) and a final
+ * row / -- utils.py:1025-1037, wired at simple_vit.py:56-57.  Same layouts as nrv_attn_fwd.
+ *   scalings fp32 [B, H, 7, N]: the row / column scaling vectors a1 b1 a2 b2 a3 b3 a4 (P = diag(a) softmax(S) diag(b)),
+ *   saved with lse for the backward.  dh == 64, N <= 256.
+ *   Backward scratch: nrv_attn_sinkhorn_bwd_workspace(B, N, H) bytes (bf16 dS^T and P^T per head). */
+int nrv_attn_sinkhorn_fwd(const void* qkv_bf16, void* out_bf16, float* lse, float* scalings,
+                          int B, int N, int H, int dh, float scale, void* stream);
+size_t nrv_attn_sinkhorn_bwd_workspace(int B, int N, int H);
+int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16, const float* lse, const float* scalings,
+                          void* dqkv_bf16, void* workspace, size_t workspace_bytes,
+                          int B, int N, int H, int dh, float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Patch unfold (replaces einops Rearrange 'b c (h p1) (w p2) -> b h w (p1 p2 c)' simple_vit.py:126-129,
  * and the im2col implied by Conv2d(k=s=p) vit.py:237-242,323).

@@ -43,6 +43,10 @@ SIGNATURES = {
     "nrv_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "nrv_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "nrv_attn_sinkhorn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "nrv_attn_sinkhorn_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "nrv_attn_sinkhorn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "nrv_patch_unfold": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "nrv_cast_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "nrv_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

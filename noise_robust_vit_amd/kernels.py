@@ -257,6 +257,36 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int
     return dqkv
 
 
+def attn_sinkhorn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
+    """robust=True attention (utils.py:1025-1037): returns (out bf16, lse fp32 [B,H,N], scalings fp32 [B,H,7,N])."""
+    _bf16(qkv, "qkv")
+    if not qkv.is_contiguous() or qkv.numel() != B * N * 3 * H * dh:
+        raise NrvError("attn_sinkhorn_fwd: qkv must be contiguous [B*N, 3*H*dh]")
+    out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    scal = torch.empty(B, H, 7, N, dtype=torch.float32, device=qkv.device)
+    lib = _lib.load()
+    _run("attn_sinkhorn_fwd", 4.0 * B * H * N * N * dh, 2 * B * N * H * dh * 4,
+         lambda: lib.nrv_attn_sinkhorn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), scal.data_ptr(),
+                                           B, N, H, dh, float(scale), _stream()),
+         "nrv_attn_sinkhorn_fwd")
+    return out, lse, scal
+
+
+def attn_sinkhorn_bwd(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+    _bf16(qkv, "qkv"); _bf16(dout, "dout"); _f32(lse, "lse"); _f32(scal, "scal")
+    if not (qkv.is_contiguous() and dout.is_contiguous()):
+        raise NrvError("attn_sinkhorn_bwd: operands must be contiguous")
+    dqkv = torch.empty_like(qkv)
+    lib = _lib.load()
+    ws = _workspace(lib.nrv_attn_sinkhorn_bwd_workspace(B, N, H), qkv.device)
+    _run("attn_sinkhorn_bwd", 10.0 * B * H * N * N * dh, 2 * B * N * H * dh * 7 + 2 * ws.numel(),
+         lambda: lib.nrv_attn_sinkhorn_bwd(qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), scal.data_ptr(), dqkv.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), B, N, H, dh, float(scale), _stream()),
+         "nrv_attn_sinkhorn_bwd")
+    return dqkv
+
+
 def patch_unfold(img: Tensor, p: int, layout: int) -> Tensor:
     """img [B,C,H,W] fp32|bf16 -> patches bf16 [B*(H/p)*(W/p), C*p*p]."""
     _dev(img, "img")

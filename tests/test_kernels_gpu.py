@@ -257,6 +257,42 @@ def test_attention_large_logits(dev):
     assert (out.float() - ref_o).abs().max().item() < 2 ** -6 * ref_o.abs().max().item()
 
 
+def sinkhorn_ref(qkv, B, N, H, dh, scale):
+    q, k, v = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    P = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    for _ in range(3):                                   # utils.py:1033-1035
+        P = P / P.sum(dim=-1, keepdim=True)
+        P = P / P.sum(dim=-2, keepdim=True)
+    P = P / P.sum(dim=-1, keepdim=True)                  # utils.py:1036
+    return (P @ v).permute(0, 2, 1, 3).reshape(B * N, H * dh), P
+
+
+@pytest.mark.parametrize("B,N,H", [(8, 4, 3), (2, 196, 3), (2, 197, 2), (3, 49, 2), (1, 256, 1), (2, 33, 1), (1, 1, 1)])
+def test_sinkhorn_attention_fwd_bwd(dev, B, N, H):
+    """robust=True attention (softmax + 3 x (row, column) + row normalisation) against the plain fp32 definition."""
+    k = _k()
+    dh = 64
+    scale = dh ** -0.5
+    qkv = rnd((B * N, 3 * H * dh), dev, 63, 1.0)
+    out, lse, scal = k.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
+    qr = qkv.float().requires_grad_(True)
+    ref_o, P = sinkhorn_ref(qr, B, N, H, dh, scale)
+    err = (out.float() - ref_o).abs().max().item() / ref_o.abs().max().item()
+    assert err < 2 ** -6, err                             # P and the output are bf16
+    # the saved scalings reproduce the doubly-normalised matrix: rows of diag(a4) P0 diag(b3) sum to one
+    q_, k_, _ = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    P0 = torch.softmax((q_ @ k_.transpose(-1, -2)) * scale, dim=-1)
+    P7 = scal[:, :, 6, :, None] * P0 * scal[:, :, 5, None, :]
+    assert (P7 - P.detach()).abs().max().item() < 1e-4 * P.max().item() + 1e-6
+    dout = rnd((B * N, H * dh), dev, 64, 1.0)
+    ref_o.backward(dout.float())
+    dqkv = k.attn_sinkhorn_bwd(qkv, dout, lse, scal, B, N, H, dh, scale)
+    g, r = dqkv.float().reshape(-1), qr.grad.reshape(-1)
+    rel = ((g - r).norm() / r.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
+    assert rel < 3e-2 and cos > 0.999, (rel, cos)
+
+
 # ------------------------------------------------------------------ data movement
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

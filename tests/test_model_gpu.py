@@ -46,7 +46,7 @@ def check_grads(model, ref_grads, prefix=""):
     return worst
 
 
-@pytest.mark.parametrize("robust", [False])
+@pytest.mark.parametrize("robust", [False, True])
 def test_simplevit_cfg1_against_reference_fixture(dev, golden_dir, robust):
     """BASELINE.json configs[0]: SimpleViT dim=192 depth=2 heads=3 patch=16 img=32 batch=8, reference weights."""
     from noise_robust_vit_amd import SimpleViT
