@@ -18,6 +18,7 @@ Nothing here computes with torch ops: torch supplies memory, streams and the aut
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -36,6 +37,9 @@ PARAMS_PER_LAYER = 12   # ln1_w ln1_b wqkv bqkv wo bo ln2_w ln2_b w1 b1 w2 b2
 # parameter's version counter changes (i.e. once per optimizer step).
 # ----------------------------------------------------------------------------------------------
 class WeightCache:
+    """id(tensor) -> (weakref, version, data_ptr, bf16 W, bf16 W^T).  Dead entries are purged, so temporaries such as a
+    `torch.cat` of split projection weights (lucid_vit.Attention: to_q + to_kv) do not accumulate."""
+
     def __init__(self) -> None:
         self._d = {}
 
@@ -43,13 +47,15 @@ class WeightCache:
         key = id(w)
         ent = self._d.get(key)
         ver = w._version
-        if ent is not None and ent[0] == ver and ent[1] == w.data_ptr() and (ent[3] is not None or not need_t):
-            return ent[2], ent[3]
+        if ent is not None and ent[0]() is w and ent[1] == ver and ent[2] == w.data_ptr():
+            return ent[3], ent[4]
         w2 = w.detach()
         if w2.dim() != 2:                       # Conv2d patch-embed weight [D, C, p, p] viewed as [D, C*p*p]
             w2 = w2.reshape(w2.shape[0], -1)
         wb, wt = K.cast_transpose(w2, need_t=True)
-        self._d[key] = (ver, w.data_ptr(), wb, wt)
+        if len(self._d) > 2048:
+            self._d = {k: v for k, v in self._d.items() if v[0]() is not None}
+        self._d[key] = (weakref.ref(w), ver, w.data_ptr(), wb, wt)
         return wb, wt
 
     def clear(self) -> None:
@@ -353,6 +359,56 @@ class PatchEmbedFn(torch.autograd.Function):
             sink.layer_done(-1, [weight] + ([bias] if has_bias else []))
             return (None, None, None, dpos, dcls, None, None, None)
         return (None, dw.reshape(wshape), db, dpos, dcls, None, None, None)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b through the MFMA GEMM (bf16 operands, fp32 result) for projections next to the encoder
+    (MAE `enc_to_dec` / `to_pixels`, mae.py:34-49).  x [..., K] fp32, K % 8 == 0, out_features % 8 == 0."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        if not x.is_cuda:
+            raise NrvError("noise_robust_vit_amd runs on the MI355X (HIP) device only; there is no CPU fallback")
+        shp = x.shape
+        x2 = x.detach().to(torch.float32).contiguous().reshape(-1, shp[-1])
+        xb = K.cast_bf16(x2)
+        wb, _ = WEIGHTS.get(weight, True)
+        y = K.gemm_nt(xb, wb, out_dtype=torch.float32, epilogue=EPI_BIAS if bias is not None else EPI_NONE,
+                      bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(xb)
+        ctx.meta = (weight, bias is not None, shp)
+        return y.reshape(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xb,) = ctx.saved_tensors
+        weight, has_bias, shp = ctx.meta
+        d16 = K.cast_bf16(dy.to(torch.float32).contiguous().reshape(-1, weight.shape[0]))
+        _, wt = WEIGHTS.get(weight, True)
+        dw = K.gemm_tn(d16, xb)
+        db = K.colsum(d16) if has_bias else None
+        dx = K.gemm_nt(d16, wt, out_dtype=torch.float32)
+        return dx.reshape(shp), dw, db
+
+
+class GatherTokensFn(torch.autograd.Function):
+    """tokens[b, index[b, :]] (MAE keeps a random 25 % of the tokens, mae.py:75-76); backward scatters rows back."""
+
+    @staticmethod
+    def forward(ctx, tokens, index):
+        B, n, D = tokens.shape
+        flat = (index + torch.arange(B, device=index.device)[:, None] * n).reshape(-1).contiguous()
+        out = K.gather_rows(tokens.detach().to(torch.float32).contiguous().reshape(B * n, D), flat)
+        ctx.save_for_backward(flat)
+        ctx.shape = (B, n, D, index.shape[1])
+        return out.reshape(B, index.shape[1], D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (flat,) = ctx.saved_tensors
+        B, n, D, k = ctx.shape
+        d = K.scatter_rows(dy.to(torch.float32).contiguous().reshape(B * k, D), flat, B * n)
+        return d.reshape(B, n, D), None
 
 
 def flat_layer_params(layers: Sequence[Sequence[Optional[Tensor]]]) -> List[Optional[Tensor]]:

@@ -1,0 +1,120 @@
+"""lucidrains-style `ViT` (class token, learned positions, `to_q` / `to_kv` split, biased `to_out`) on the HIP path.
+
+This is the encoder family the reference's `MAE` wrapper expects (`mae.py:29-31`: `to_patch_embedding[:2]`,
+`pos_embedding [1, n+1, d]`, `transformer`); module tree, constructor arguments and state_dict keys follow
+`/root/reference/vit_pytorch_robust/learnable_memory_vit.py:30-151` (FeedForward keys `net.0,1,4`; Attention keys
+`norm, to_q, to_kv, to_out.0`; `Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)`; `ViT(...)`).
+Dropout arguments are accepted, p = 0 is what the fused path implements.  The adapter / memory arguments of the
+reference's `forward(x, attn_mask, memories)` are outside the hot path and must be None.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from ._lib import PATCH_P1P2C
+from .encoder import AttnHalfFn, BlockMeta, EncoderStackFn, MlpHalfFn, PatchEmbedFn
+from .simple_vit import PatchUnfold, _pair
+
+
+def _no_dropout(p: float) -> None:
+    if p != 0.0:
+        raise NotImplementedError(f"dropout={p}: the fused HIP path implements p=0 only")
+
+
+class PatchUnfoldFlat(PatchUnfold):
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (learnable_memory_vit.py:120)."""
+
+    def forward(self, img):
+        x = super().forward(img)
+        return x.reshape(x.shape[0], -1, x.shape[-1])
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+        self.p = dropout
+        self._meta = BlockMeta(heads=1, dim_head=64, eps=self.net[0].eps)
+
+    def layer_params(self):
+        n = self.net
+        return [n[0].weight, n[0].bias, n[1].weight, n[1].bias, n[4].weight, n[4].bias]
+
+    def forward(self, x):
+        _no_dropout(self.p if self.training else 0.0)
+        return MlpHalfFn.apply(x, self._meta, *self.layer_params())
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads, self.dim_head, self.scale, self.p = heads, dim_head, dim_head ** -0.5, dropout
+        self.norm = nn.LayerNorm(dim)
+        self.attend = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim, inner * 2, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+        self._meta = BlockMeta(heads=heads, dim_head=dim_head, eps=self.norm.eps)
+
+    def layer_params(self):
+        # one [3*inner, dim] projection for the fused QKV GEMM; autograd splits the gradient back through the cat
+        wqkv = torch.cat([self.to_q.weight, self.to_kv.weight], dim=0)
+        return [self.norm.weight, self.norm.bias, wqkv, None, self.to_out[0].weight, self.to_out[0].bias]
+
+    def forward(self, x, attn_mask=None, memories=None):
+        if attn_mask is not None or memories is not None:
+            raise NotImplementedError("attention masks / memory tokens are outside the encoder hot path")
+        _no_dropout(self.p if self.training else 0.0)
+        return AttnHalfFn.apply(x, self._meta, *self.layer_params())
+
+
+class Transformer(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            nn.ModuleList([Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout), FeedForward(dim, mlp_dim, dropout=dropout)])
+            for _ in range(depth))
+        self.p = dropout
+        self._meta = BlockMeta(heads=heads, dim_head=dim_head, eps=1e-5)
+
+    def forward(self, x, attn_mask=None, memories=None):
+        if attn_mask is not None or memories is not None:
+            raise NotImplementedError("attention masks / memory tokens are outside the encoder hot path")
+        _no_dropout(self.p if self.training else 0.0)
+        flat = []
+        for attn, ff in self.layers:
+            flat += attn.layer_params() + ff.layer_params()
+        return EncoderStackFn.apply(x, self._meta, *flat)
+
+
+class ViT(nn.Module):
+    def __init__(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool='cls', channels=3,
+                 dim_head=64, dropout=0., emb_dropout=0.):
+        super().__init__()
+        ih, iw = _pair(image_size)
+        ph, pw = _pair(patch_size)
+        assert ih % ph == 0 and iw % pw == 0, 'Image dimensions must be divisible by the patch size.'
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        if ph != pw:
+            raise NotImplementedError("square patches only")
+        num_patches = (ih // ph) * (iw // pw)
+        self.patch = ph
+        self.to_patch_embedding = nn.Sequential(PatchUnfoldFlat(ph, pw), nn.Linear(channels * ph * pw, dim))
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
+
+    def img_to_tokens(self, img):
+        _no_dropout(self.dropout.p if self.training else 0.0)
+        lin = self.to_patch_embedding[1]
+        return PatchEmbedFn.apply(img, lin.weight, lin.bias, self.pos_embedding, self.cls_token, self.patch, PATCH_P1P2C, None)
+
+    def forward(self, img):
+        x = self.transformer(self.img_to_tokens(img))
+        return self.mlp_head(x[:, 0])

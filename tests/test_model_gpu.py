@@ -186,3 +186,31 @@ def test_state_dict_roundtrip_and_legacy_mlp_keys(dev):
     # a version-1 checkpoint (no metadata) with linear_1/linear_2 names must load (vit.py:55-84)
     m.load_state_dict(legacy)
     assert torch.equal(m.encoder.layers.encoder_layer_0.mlp[0].weight.data, legacy["encoder.layers.encoder_layer_0.mlp.linear_1.weight"])
+
+
+def test_mae_against_shimmed_reference_fixture(dev, golden_dir):
+    """BASELINE.json configs[4] path at reduced size: MAE over a lucidrains-style ViT, 75 % mask.
+    Fixture = the reference's mae.py run with the shim of SURVEY.md §8c (5) ("reference MAE + shimmed missing import")."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd.mae import MAE
+    g = load_npz(f"{golden_dir}/mae_small.npz") if False else dict(np.load(f"{golden_dir}/mae_small.npz"))
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")}
+    enc = ViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256)
+    mae = MAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=1, decoder_dim_head=64)
+    assert sorted(mae.state_dict()) == sorted(sd)
+    mae.load_state_dict(sd)
+    mae = mae.to(dev).train()
+    loss = mae(torch.from_numpy(g["img"]).to(dev), rand_indices=torch.from_numpy(g["rand_indices"]).to(dev))
+    loss.backward()
+    ref = float(g["loss"])
+    print(f"MAE loss {loss.item():.6f} vs reference {ref:.6f}")
+    assert abs(loss.item() - ref) < 5e-3 * abs(ref)
+    params = dict(mae.named_parameters())
+    for k, v in g.items():
+        if k.startswith("g."):
+            r = torch.from_numpy(v).reshape(-1)
+            gk = params[k[2:]].grad.detach().float().cpu().reshape(-1)
+            rel = ((gk - r).norm() / r.norm()).item()
+            assert rel < GRAD_RELL2_TOL, (k, rel)
+        if k.startswith("gn."):
+            assert params[k[3:]].grad is not None, k

@@ -66,3 +66,20 @@ def test_cross_entropy_label_smoothing_matches_torch():
     y = torch.randint(0, 100, (16,), generator=g)
     ref = torch.nn.functional.cross_entropy(logits, y, label_smoothing=0.1)
     assert abs(O.cross_entropy_ls(logits, y).item() - ref.item()) < 1e-6
+
+
+def test_mae_oracle_against_shimmed_reference_fixture(golden_dir):
+    """mae.py:51-118 with the lucidrains-style encoder; fixture = reference MAE + shimmed missing import."""
+    from oracle import mae_oracle as M
+    g = np.load(f"{golden_dir}/mae_small.npz")
+    assert "shimmed" in str(g["meta"])
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    loss = M.mae_forward(leaves, torch.from_numpy(g["img"]), torch.from_numpy(g["rand_indices"]),
+                         patch_size=16, enc_heads=2, dec_heads=1)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    for k in g.files:
+        if k.startswith("g."):
+            r = torch.from_numpy(g[k])
+            assert (leaves[k[2:]].grad - r).norm() / r.norm() < 1e-5, k
