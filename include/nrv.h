@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 1
+#define NRV_ABI_VERSION 2
 
 /* dtype codes */
 #define NRV_F32 0
@@ -108,12 +108,15 @@ int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
  *   A [T,M] bf16 lda; B [T,N] bf16 ldb; C fp32 ldc; beta is 0 or 1.
  *   M % 8 == 0, N % 8 == 0; a_group/a_group_stride/a_row_offset remap the rows of A exactly as
  *   the NT output remap does (0 = identity) so that dY laid out with a class-token slot can be used.
+ *   dbias (optional, fp32 [M]): the bias gradient of the same Linear, dbias[m] = dbias_beta*dbias[m] + sum_t A[t,m],
+ *   computed on the MFMA from the A tiles the kernel already streams (no second pass over dY).
  *   workspace: nrv_gemm_tn_workspace(M, N, T) bytes.
  * ---------------------------------------------------------------------------------------- */
 size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T);
 int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
                      float* C, int64_t ldc, int64_t M, int64_t N, int64_t T, float beta,
                      int64_t a_group, int64_t a_group_stride, int64_t a_row_offset,
+                     float* dbias, float dbias_beta,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Column sum (bias gradient of nn.Linear's backward): out[n] = beta*out[n] + sum_t X[t,n].

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("NRV_LIB_PATH") or os.path.join(_HERE, "lib", "libnrv_
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -37,7 +37,7 @@ SIGNATURES = {
     "nrv_gemm_tn_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "nrv_gemm_tn_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                  c_int64, c_int64, c_int64, c_float, c_int64, c_int64, c_int64,
-                                 c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "nrv_colsum_workspace": (c_size_t, [c_int64, c_int64]),
     "nrv_colsum_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
     "nrv_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

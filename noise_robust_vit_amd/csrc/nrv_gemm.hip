@@ -52,6 +52,7 @@ struct TileCfg {
 };
 using Cfg256 = TileCfg<2, 4, 8, 4>;
 using Cfg192 = TileCfg<2, 2, 6, 4>;
+using Cfg128 = TileCfg<2, 4, 4, 4>;      // 128x256 tile, 8 waves: finer tile granularity for N = 768 shapes
 constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
 constexpr int EPI_PATCH_BYTES = 16 * EPI_ROW_F32 * 4;   // 4352 B per wave
 
@@ -86,6 +87,7 @@ struct GemmTNParams {
     int splits, kt_per_split;     // K-tiles (of 64 token rows) per split
     int a_group, a_group_stride, a_row_offset;
     long long slab_stride;        // elements between split slabs (0 when splits == 1)
+    float* bias_ws;               // optional [splits][M] column sums of A (bias gradient), nullptr = off
     EpiParams e;
 };
 
@@ -385,6 +387,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // fused bias gradient: db[m] = sum_t A[t,m] = (ones . A) on the MFMA; only the first column tile's workgroups do
+    // it, and each of the 4 column waves takes two of the 8 row blocks (2 extra MFMAs per k-step)
+    const bool do_bias = p.bias_ws != nullptr && tn == 0;
+    const u32x4_t ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
+    f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+
     auto ld_a = [&](const char* sa, int ks, int mi) {
         const char* q = sa + ((a_tr ^ (mi << 5)) + ks * (32 * 512));
         return cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
@@ -428,6 +437,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[2 * mp + j][ni] = mfma16(bfr[ks & 1][ni], af[g & 1][j], acc[2 * mp + j][ni]);
+            if (do_bias && mp == wc) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, af[g & 1][j], accb[j]);
+            }
             if (more && g < 4) {
                 dma_one(cur ^ 1, kt + 1, 2 * g);
                 dma_one(cur ^ 1, kt + 1, 2 * g + 1);
@@ -435,6 +448,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
         }
     }
     __syncthreads();
+    if (do_bias && lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wr * 128 + (2 * wc + j) * 16 + lane;
+            if (m < M) p.bias_ws[(long long)split * M + m] = accb[j][0];
+        }
+    }
     EpiParams e = p.e;
     e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
     epilogue<NRV_EPI_NONE, true, true, 8>(acc, smem, e, m0 + wr * 128, n0 + wc * 64, lane, wave);
@@ -442,7 +462,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
 
 // C = beta * C + sum_s slab[s]
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int splits,
-                                     float* __restrict__ C, long long ldc, int M, int N, float beta) {
+                                     float* __restrict__ C, long long ldc, int M, int N, float beta,
+                                     const float* __restrict__ bias_ws, float* __restrict__ dbias, float dbias_beta) {
+    if (bias_ws != nullptr) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += bias_ws[(long long)k * M + i];
+            dbias[i] = dbias_beta != 0.f ? dbias_beta * dbias[i] + s : s;
+        }
+    }
+    if (slabs == nullptr) return;
     const long long n4 = N >> 2;
     const long long total = (long long)M * n4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -491,14 +520,16 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
 // tile selection: NRV_GEMM_TILE=256|192 forces a configuration (bench / tests); default = heuristic
 int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("NRV_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (forced == 256 || forced == 192) return forced;
+    if (forced == 256 || forced == 192 || forced == 128) return forced;
     (void)M; (void)N; (void)K;
     return 256;      // measured on the ViT-B/16 shapes: Cfg192 is LDS-DMA-bandwidth bound (2 x 40 KiB per K-step per CU)
 }
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
-    if (nt_tile_choice(p.e.M, p.e.N, p.K) == 256) return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
+    const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
+    if (tc == 256) return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
+    if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32>(p, s);
     return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32>(p, s);
 }
 
@@ -582,12 +613,13 @@ extern "C" int nrv_debug_read_stamps(unsigned long long* host_out, size_t count)
 extern "C" size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T) {
     if (M <= 0 || N <= 0 || T <= 0) return 0;
     const int s = tn_splits(M, N, T);
-    return (size_t)s * (size_t)M * (size_t)N * 4;   // covers the beta == 1 case of a single split too
+    return (size_t)s * (size_t)M * (size_t)N * 4 + (size_t)s * (size_t)M * 4;   // C slabs (also the beta == 1 single-split case) + bias slabs
 }
 
 extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
                                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t T, float beta,
                                 int64_t a_group, int64_t a_group_stride, int64_t a_row_offset,
+                                float* dbias, float dbias_beta,
                                 void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !B || !C) return NRV_ERR_NULL;
     if (M <= 0 || N <= 0 || T <= 0) return NRV_ERR_SHAPE;
@@ -603,9 +635,11 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     const int64_t a_rows = a_group > 0 ? (int64_t)kt_per_split * BK * a_group_stride / a_group + a_group_stride : (int64_t)kt_per_split * BK;
     if (a_rows * lda * 2 >= 0x7fffffffll || (int64_t)kt_per_split * BK * ldb * 2 >= 0x7fffffffll) return NRV_ERR_SHAPE;
     const bool direct = splits == 1 && beta == 0.f;
-    const size_t need = direct ? 0 : (size_t)splits * (size_t)M * (size_t)N * 4;
-    if (!direct && (!workspace || workspace_bytes < need)) return NRV_ERR_WORKSPACE;
-    if (!direct && !nrv_aligned16(workspace)) return NRV_ERR_ALIGN;
+    const size_t slab_bytes = direct ? 0 : (size_t)splits * (size_t)M * (size_t)N * 4;
+    const size_t need = slab_bytes + (dbias ? (size_t)splits * (size_t)M * 4 : 0);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return NRV_ERR_WORKSPACE;
+    if (need > 0 && !nrv_aligned16(workspace)) return NRV_ERR_ALIGN;
+    if (dbias && dbias_beta != 0.f && dbias_beta != 1.f) return NRV_ERR_SHAPE;
 
     GemmTNParams p;
     p.A = static_cast<const bf16_t*>(A);
@@ -621,18 +655,21 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.e.out_group = 0; p.e.out_group_stride = 0; p.e.out_row_offset = 0;
     if (direct) { p.e.C = C; p.e.ldc = ldc; p.slab_stride = 0; }
     else { p.e.C = workspace; p.e.ldc = N; p.slab_stride = (long long)M * N; }
+    p.bias_ws = dbias ? reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes) : nullptr;
 
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int attr = set_lds(gemm_tn_kernel, GEMM_LDS_BYTES);
     if (attr != 0) return attr;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, p);
     NRV_CHECK_LAUNCH();
-    if (!direct) {
-        const long long total4 = (long long)M * (N >> 2);
+    if (!direct || dbias) {
+        const long long total4 = direct ? (long long)nrv_cdiv(M, 4) : (long long)M * (N >> 2);
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s,
-                           static_cast<const float*>(workspace), (long long)M * N, splits, C, (long long)ldc, (int)M, (int)N, beta);
+                           direct ? nullptr : static_cast<const float*>(workspace), (long long)M * N, splits, C, (long long)ldc,
+                           (int)M, (int)N, beta, static_cast<const float*>(p.bias_ws), dbias, dbias_beta);
         NRV_CHECK_LAUNCH();
     }
     return 0;

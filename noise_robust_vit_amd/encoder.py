@@ -90,6 +90,17 @@ def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
     return None, 0.0
 
 
+def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
+    """Weight and bias gradient of y = x W^T + b in ONE kernel: dW = dy^T x on the MFMA, db = colsum(dy) fused."""
+    tw, bw = _grad_target(meta, w)
+    if b is None:
+        return K.gemm_tn(dy16, x16, out=tw, beta=bw), None
+    tb, bb = _grad_target(meta, b)
+    if tb is None:
+        return K.gemm_tn(dy16, x16, out=tw, beta=bw, want_dbias=True)
+    return K.gemm_tn(dy16, x16, out=tw, beta=bw, dbias=tb, dbias_beta=bb)
+
+
 # ----------------------------------------------------------------------------------------------
 # attention half
 # ----------------------------------------------------------------------------------------------
@@ -124,12 +135,7 @@ def attn_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, B: int, N: int, m
     _, wo_t = WEIGHTS.get(wo, True)
     _, wqkv_t = WEIGHTS.get(wqkv, True)
     # out-proj:  y = o Wo^T (+bo) (+x)
-    t, beta = _grad_target(meta, wo)
-    dwo = K.gemm_tn(dy16, o, out=t, beta=beta)
-    dbo = None
-    if bo is not None:
-        t, beta = _grad_target(meta, bo)
-        dbo = K.colsum(dy16, out=t, beta=beta)
+    dwo, dbo = _dw_db(meta, dy16, o, wo, bo)
     do = K.gemm_nt(dy16, wo_t, out_dtype=torch.bfloat16)
     scale = dh ** -0.5
     if meta.robust:
@@ -137,12 +143,7 @@ def attn_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, B: int, N: int, m
         dqkv = sinkhorn.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
     else:
         dqkv = K.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
-    t, beta = _grad_target(meta, wqkv)
-    dwqkv = K.gemm_tn(dqkv, xn, out=t, beta=beta)
-    dbqkv = None
-    if bqkv is not None:
-        t, beta = _grad_target(meta, bqkv)
-        dbqkv = K.colsum(dqkv, out=t, beta=beta)
+    dwqkv, dbqkv = _dw_db(meta, dqkv, xn, wqkv, bqkv)
     dxn = K.gemm_nt(dqkv, wqkv_t, out_dtype=torch.bfloat16)
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
@@ -175,19 +176,9 @@ def mlp_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, meta: BlockMeta,
         dy16 = K.cast_bf16(dy32)
     _, w2_t = WEIGHTS.get(w2, True)
     _, w1_t = WEIGHTS.get(w1, True)
-    t, beta = _grad_target(meta, w2)
-    dw2 = K.gemm_tn(dy16, h, out=t, beta=beta)
-    db2 = None
-    if b2 is not None:
-        t, beta = _grad_target(meta, b2)
-        db2 = K.colsum(dy16, out=t, beta=beta)
+    dw2, db2 = _dw_db(meta, dy16, h, w2, b2)
     du = K.gemm_nt(dy16, w2_t, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
-    t, beta = _grad_target(meta, w1)
-    dw1 = K.gemm_tn(du, xn, out=t, beta=beta)
-    db1 = None
-    if b1 is not None:
-        t, beta = _grad_target(meta, b1)
-        db1 = K.colsum(du, out=t, beta=beta)
+    dw1, db1 = _dw_db(meta, du, xn, w1, b1)
     dxn = K.gemm_nt(du, w1_t, out_dtype=torch.bfloat16)
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
@@ -385,8 +376,10 @@ class LinearFn(torch.autograd.Function):
         weight, has_bias, shp = ctx.meta
         d16 = K.cast_bf16(dy.to(torch.float32).contiguous().reshape(-1, weight.shape[0]))
         _, wt = WEIGHTS.get(weight, True)
-        dw = K.gemm_tn(d16, xb)
-        db = K.colsum(d16) if has_bias else None
+        if has_bias:
+            dw, db = K.gemm_tn(d16, xb, want_dbias=True)
+        else:
+            dw, db = K.gemm_tn(d16, xb), None
         dx = K.gemm_nt(d16, wt, out_dtype=torch.float32)
         return dx.reshape(shp), dw, db
 

@@ -192,8 +192,12 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
 
 
 def gemm_tn(A: Tensor, B: Tensor, *, out: Optional[Tensor] = None, beta: float = 0.0,
-            a_group: int = 0, a_group_stride: int = 0, a_row_offset: int = 0, T: Optional[int] = None) -> Tensor:
-    """C[M,N] fp32 = beta*C + sum_t A[t,M] B[t,N]  (weight gradient).  `T` limits the token rows used (default B.shape[0])."""
+            a_group: int = 0, a_group_stride: int = 0, a_row_offset: int = 0, T: Optional[int] = None,
+            dbias: Optional[Tensor] = None, dbias_beta: float = 0.0, want_dbias: bool = False):
+    """C[M,N] fp32 = beta*C + sum_t A[t,M] B[t,N]  (weight gradient).  `T` limits the token rows used (default B.shape[0]).
+
+    With `want_dbias` (or a `dbias` output) the bias gradient sum_t A[t,:] is produced by the same kernel and the
+    call returns (C, dbias)."""
     _bf16(A, "A"); _bf16(B, "B")
     Ta, M, lda = _rows2d(A, "A")
     Tb, N, ldb = _rows2d(B, "B")
@@ -205,12 +209,20 @@ def gemm_tn(A: Tensor, B: Tensor, *, out: Optional[Tensor] = None, beta: float =
         beta = 0.0
     _f32(out, "out")
     _, _, ldc = _rows2d(out, "out")
+    if want_dbias and dbias is None:
+        dbias = torch.empty(M, dtype=torch.float32, device=A.device)
+        dbias_beta = 0.0
+    if dbias is not None:
+        _f32(dbias, "dbias")
     lib = _lib.load()
     ws = _workspace(lib.nrv_gemm_tn_workspace(M, N, T), A.device)
     _run("gemm_tn", 2.0 * M * N * T, 2 * T * (M + N) + 4 * M * N,
          lambda: lib.nrv_gemm_tn_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, T, float(beta),
-                                      int(a_group), int(a_group_stride), int(a_row_offset), ws.data_ptr(), ws.numel(), _stream()),
+                                      int(a_group), int(a_group_stride), int(a_row_offset),
+                                      _ptr(dbias), float(dbias_beta), ws.data_ptr(), ws.numel(), _stream()),
          "nrv_gemm_tn_bf16")
+    if dbias is not None:
+        return out, dbias
     return out
 
 

@@ -182,6 +182,12 @@ def test_gemm_tn(dev, T, M, N):
     assert rel_err(c, ref) < 2e-5 * math.sqrt(T), rel_err(c, ref)
     c2 = k.gemm_tn(A, B, out=c.clone(), beta=1.0)
     assert rel_err(c2, 2 * ref) < 2e-5 * math.sqrt(T)
+    # fused bias gradient (column sums of A) from the same kernel
+    c3, db = k.gemm_tn(A, B, want_dbias=True)
+    assert torch.equal(c3, c)
+    assert rel_err(db, A.float().sum(0)) < 1e-5 * math.sqrt(T), rel_err(db, A.float().sum(0))
+    _, db2 = k.gemm_tn(A, B, dbias=db.clone(), dbias_beta=1.0)
+    assert rel_err(db2, 2 * A.float().sum(0)) < 1e-5 * math.sqrt(T)
 
 
 def test_gemm_tn_identity_asymmetric(dev):
