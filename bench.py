@@ -183,13 +183,19 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        # instrumented steps: HIP events around every C-ABI launch on the compute stream
+        # instrumented steps: HIP events around every C-ABI launch on the compute stream.  The dW / dX two-stream
+        # overlap is switched off here so that each kernel's duration is its own (overlapped kernels share the chip
+        # and their event spans would double-count); the timed region above runs with the overlap on.
+        from noise_robust_vit_amd import encoder as _enc
+        _overlap_was = _enc.OVERLAP_DW
+        _enc.set_overlap(False)
         with K.LaunchProfile() as prof:
             for _ in range(2):
                 trainer.forward_backward(x, y) if world == 1 else None
                 if world == 1:
                     trainer.opt.zero_grad(set_to_none=True)
         summ = prof.summary() if world == 1 else {}
+        _enc.set_overlap(_overlap_was)
         if "gemm_nt" in summ:
             gnt = summ["gemm_nt"]
             ach = gnt["flops"] / (gnt["ms"] * 1e-3) / 1e12

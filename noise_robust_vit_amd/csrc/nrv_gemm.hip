@@ -109,41 +109,56 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
                                          int lane, int wave) {
     float* stg = reinterpret_cast<float*>(smem + wave * EPI_PATCH_BYTES);
     const int wc_row = lane & 15, wg = lane >> 4;       // write side: row within slab, column group
-    const int rcol4 = lane & 15, rrow = lane >> 4;      // read side: float4 column, row phase
-    const int ncol = col_base + rcol4 * 4;
-    const bool col_ok = ncol < e.N;
+    // read side: a lane owns CW consecutive columns of one row, so that every global access is 16 bytes wide
+    // (bf16 results: 8 columns = one dwordx4 store -- the store tail is issue-bound, guide T21; fp32: 4 columns)
+    constexpr int CW = OUT_F32 ? 4 : 8;
+    constexpr int V = CW / 4;                           // float4 pieces per lane
+    constexpr int LPR = 64 / CW;                        // lanes per 64-column row
+    constexpr int RPI = 64 / LPR;                       // rows covered per pass
+    constexpr int NIT = 16 / RPI;                       // passes per 16-row slab
+    const int rcol = lane % LPR, rrow = lane / LPR;
+    const int ncol = col_base + rcol * CW;
+    const bool col_ok = ncol < e.N;                     // N % 8 == 0: a chunk is entirely inside or outside
     constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
     constexpr bool AUX32 = EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32;
     constexpr int HALF = (MI + 1) / 2;
 
-    f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t bias4[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) bias4[v] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (EPI == NRV_EPI_BIAS || EPI == NRV_EPI_BIAS_GELU || EPI == NRV_EPI_BIAS_RESIDUAL) {
-        if (e.bias != nullptr && col_ok) bias4 = *reinterpret_cast<const f32x4_t*>(e.bias + ncol);
+        if (e.bias != nullptr && col_ok) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) bias4[v] = *reinterpret_cast<const f32x4_t*>(e.bias + ncol + 4 * v);
+        }
     }
 
 #pragma unroll
     for (int h0 = 0; h0 < MI; h0 += HALF) {
         // Epilogue operands (residual stream / saved pre-activation) do not depend on the LDS transposition:
-        // issue the loads of half the wave's block up front so that 4 x HALF requests per lane are in flight
+        // issue the loads of half the wave's block up front so that many requests per lane are in flight
         // (one dependent load per slab made this phase latency-bound: 27 us per 256x256 fp32-residual tile).
-        f32x4_t aux32[AUX32 ? HALF : 1][4];
-        u32x2_t aux16[(HAS_AUX && !AUX32) ? HALF : 1][4];
+        f32x4_t aux32[AUX32 ? HALF : 1][NIT][V];
+        u32x2_t aux16[(HAS_AUX && !AUX32) ? HALF : 1][NIT][V];
         if (HAS_AUX) {
 #pragma unroll
             for (int mh = 0; mh < HALF; ++mh) {
                 const int mi = h0 + mh;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = row_base + mi * 16 + rrow + 4 * i;
+                for (int i = 0; i < NIT; ++i) {
+                    const int m = row_base + mi * 16 + rrow + RPI * i;
                     const bool ok = mi < MI && m < e.M && col_ok;
                     const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
                     const long long arow = (EPI == NRV_EPI_BIAS_RESIDUAL && e.aux_row_mod > 0) ? (long long)(m % e.aux_row_mod) : orow;
-                    if (AUX32) {
-                        aux32[mh][i] = ok ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.aux) + arow * e.ld_aux + ncol)
-                                          : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    } else {
-                        aux16[mh][i] = ok ? *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + arow * e.ld_aux + ncol)
-                                          : u32x2_t{0u, 0u};
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        if (AUX32) {
+                            aux32[mh][i][v] = ok ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.aux) + arow * e.ld_aux + ncol + 4 * v)
+                                                 : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            aux16[mh][i][v] = ok ? *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + arow * e.ld_aux + ncol + 4 * v)
+                                                 : u32x2_t{0u, 0u};
+                        }
                     }
                 }
             }
@@ -156,40 +171,57 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
                 for (int ni = 0; ni < 4; ++ni)
                     *reinterpret_cast<f32x4_t*>(stg + wc_row * EPI_ROW_F32 + ni * 16 + wg * 4) = acc[mi][ni];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = rrow + 4 * i;
-                    f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + r * EPI_ROW_F32 + rcol4 * 4);
+                for (int i = 0; i < NIT; ++i) {
+                    const int r = rrow + RPI * i;
+                    f32x4_t val[V];
+#pragma unroll
+                    for (int v = 0; v < V; ++v) val[v] = *reinterpret_cast<const f32x4_t*>(stg + r * EPI_ROW_F32 + rcol * CW + 4 * v);
                     const int m = row_base + mi * 16 + r;
                     if (m < e.M && col_ok) {
-                        v += bias4;
                         const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
-                        if (EPI == NRV_EPI_BIAS_GELU) {
-                            if (e.aux_out != nullptr) {
-                                u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                                *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.aux_out) + orow * e.ld_aux_out + ncol) = pk;
-                            }
+                        unsigned pk[2 * V], pku[2 * V];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = gelu_fwd(v[j]);
-                        }
-                        if (EPI == NRV_EPI_BIAS_RESIDUAL) {
-                            if (AUX32) {
-                                v += aux32[mh][i];
+                        for (int v = 0; v < V; ++v) {
+                            f32x4_t x = val[v] + bias4[v];
+                            if (EPI == NRV_EPI_BIAS_GELU) {
+                                pku[2 * v] = pack_bf16x2(x[0], x[1]);
+                                pku[2 * v + 1] = pack_bf16x2(x[2], x[3]);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) x[j] = gelu_fwd(x[j]);
+                            }
+                            if (EPI == NRV_EPI_BIAS_RESIDUAL) {
+                                if (AUX32) {
+                                    x += aux32[mh][i][v];
+                                } else {
+                                    const u32x2_t a = aux16[mh][i][v];
+                                    x[0] += bf16lo_to_f32(a[0]); x[1] += bf16hi_to_f32(a[0]);
+                                    x[2] += bf16lo_to_f32(a[1]); x[3] += bf16hi_to_f32(a[1]);
+                                }
+                            }
+                            if (EPI == NRV_EPI_DGELU) {
+                                const u32x2_t a = aux16[mh][i][v];
+                                x[0] *= gelu_grad(bf16lo_to_f32(a[0])); x[1] *= gelu_grad(bf16hi_to_f32(a[0]));
+                                x[2] *= gelu_grad(bf16lo_to_f32(a[1])); x[3] *= gelu_grad(bf16hi_to_f32(a[1]));
+                            }
+                            if (OUT_F32) {
+                                *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.C) + orow * e.ldc + ncol + 4 * v) = x;
                             } else {
-                                const u32x2_t a = aux16[mh][i];
-                                v[0] += bf16lo_to_f32(a[0]); v[1] += bf16hi_to_f32(a[0]);
-                                v[2] += bf16lo_to_f32(a[1]); v[3] += bf16hi_to_f32(a[1]);
+                                pk[2 * v] = pack_bf16x2(x[0], x[1]);
+                                pk[2 * v + 1] = pack_bf16x2(x[2], x[3]);
                             }
                         }
-                        if (EPI == NRV_EPI_DGELU) {
-                            const u32x2_t a = aux16[mh][i];
-                            v[0] *= gelu_grad(bf16lo_to_f32(a[0])); v[1] *= gelu_grad(bf16hi_to_f32(a[0]));
-                            v[2] *= gelu_grad(bf16lo_to_f32(a[1])); v[3] *= gelu_grad(bf16hi_to_f32(a[1]));
+                        if (!OUT_F32) {      // V == 2: one 16-byte store of 8 bf16
+                            const u32x4_t o = {pk[0], pk[1], pk[2 * V - 2], pk[2 * V - 1]};
+                            *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(e.C) + orow * e.ldc + ncol) = o;
                         }
-                        if (OUT_F32) {
-                            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.C) + orow * e.ldc + ncol) = v;
-                        } else {
-                            u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                            *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.C) + orow * e.ldc + ncol) = pk;
+                        if (EPI == NRV_EPI_BIAS_GELU && e.aux_out != nullptr) {
+                            if (V == 2) {
+                                const u32x4_t o = {pku[0], pku[1], pku[2 * V - 2], pku[2 * V - 1]};
+                                *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(e.aux_out) + orow * e.ld_aux_out + ncol) = o;
+                            } else {
+                                const u32x2_t o = {pku[0], pku[1]};
+                                *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.aux_out) + orow * e.ld_aux_out + ncol) = o;
+                            }
                         }
                     }
                 }

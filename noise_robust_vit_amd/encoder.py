@@ -18,6 +18,7 @@ Nothing here computes with torch ops: torch supplies memory, streams and the aut
 """
 from __future__ import annotations
 
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
@@ -30,6 +31,7 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_NO
 Tensor = torch.Tensor
 
 PARAMS_PER_LAYER = 12   # ln1_w ln1_b wqkv bqkv wo bo ln2_w ln2_b w1 b1 w2 b2
+GRAD_STREAM_BF16 = os.environ.get("NRV_GRAD_STREAM", "fp32") == "bf16"
 
 
 # ----------------------------------------------------------------------------------------------
@@ -90,15 +92,53 @@ def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
     return None, 0.0
 
 
+# The weight-gradient GEMM (dW = dy^T x) and the input-gradient GEMM (dx = dy W) of one Linear only share their
+# input dy.  They are enqueued on two HIP streams so that the hardware dispatcher fills one kernel's partial last
+# round of tiles (591 tiles on 256 CUs = 2.3 rounds) with the other kernel's workgroups, and so that the two kernels'
+# epilogue bursts hit HBM out of phase.  NRV_OVERLAP_DW=0 puts everything back on one stream.
+OVERLAP_DW = os.environ.get("NRV_OVERLAP_DW", "0") != "0"      # measured on ViT-B/16: 42.5 ms with, 41.3 ms without -> off by default
+_SIDE = {}
+
+
+def set_overlap(on: bool) -> None:
+    """Toggle the two-stream dW / dX overlap (bench.py turns it off while timing individual kernels)."""
+    global OVERLAP_DW
+    _join_side()
+    OVERLAP_DW = bool(on)
+
+
+def _side_stream() -> "torch.cuda.Stream":
+    dev = torch.cuda.current_device()
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _join_side() -> None:
+    """Order everything launched on the main stream from here on after the side-stream weight-gradient GEMMs."""
+    if OVERLAP_DW and _SIDE:
+        torch.cuda.current_stream().wait_stream(_side_stream())
+
+
 def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
     """Weight and bias gradient of y = x W^T + b in ONE kernel: dW = dy^T x on the MFMA, db = colsum(dy) fused."""
     tw, bw = _grad_target(meta, w)
-    if b is None:
-        return K.gemm_tn(dy16, x16, out=tw, beta=bw), None
-    tb, bb = _grad_target(meta, b)
-    if tb is None:
-        return K.gemm_tn(dy16, x16, out=tw, beta=bw, want_dbias=True)
-    return K.gemm_tn(dy16, x16, out=tw, beta=bw, dbias=tb, dbias_beta=bb)
+    tb, bb = _grad_target(meta, b) if b is not None else (None, 0.0)
+
+    def run():
+        if b is None:
+            return K.gemm_tn(dy16, x16, out=tw, beta=bw), None
+        if tb is None:
+            return K.gemm_tn(dy16, x16, out=tw, beta=bw, want_dbias=True)
+        return K.gemm_tn(dy16, x16, out=tw, beta=bw, dbias=tb, dbias_beta=bb)
+
+    if not OVERLAP_DW:
+        return run()
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())       # dy16 / x16 are produced on the main stream
+    with torch.cuda.stream(side):
+        return run()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -125,9 +165,11 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
     return y, (x, xn, mean, rstd, qkv, o, aux)
 
 
-def attn_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, B: int, N: int, meta: BlockMeta,
-                  ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, want_bf16: bool):
-    """Returns (dx32, dx16|None, [d ln_w, d ln_b, d wqkv, d bqkv, d wo, d bo])."""
+def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int, N: int, meta: BlockMeta,
+                  ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, want_bf16: bool, want_f32: bool = True):
+    """Returns (dx32|None, dx16|None, [d ln_w, d ln_b, d wqkv, d bqkv, d wo, d bo]).
+
+    The incoming gradient is given as fp32 (`dy32`), bf16 (`dy16`) or both; the residual add uses fp32 when present."""
     x, xn, mean, rstd, qkv, o, aux = saved
     H, dh = meta.heads, meta.dim_head
     if dy16 is None:
@@ -145,10 +187,12 @@ def attn_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, B: int, N: int, m
         dqkv = K.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
     dwqkv, dbqkv = _dw_db(meta, dqkv, xn, wqkv, bqkv)
     dxn = K.gemm_nt(dqkv, wqkv_t, out_dtype=torch.bfloat16)
+    _join_side()
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
-    dx32, dx16, dg, db = K.layernorm_bwd(dxn, x, ln_w, mean, rstd, dres=dy32 if residual else None,
-                                         want_f32=True, want_bf16=want_bf16, dgamma=tg, dbeta=tb, accumulate=bg != 0.0)
+    dres = (dy32 if dy32 is not None else dy16) if residual else None
+    dx32, dx16, dg, db = K.layernorm_bwd(dxn, x, ln_w, mean, rstd, dres=dres,
+                                         want_f32=want_f32, want_bf16=want_bf16, dgamma=tg, dbeta=tb, accumulate=bg != 0.0)
     return dx32, dx16, [dg, db, dwqkv, dbqkv, dwo, dbo]
 
 
@@ -169,8 +213,8 @@ def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residua
     return y, (x, xn, mean, rstd, u, h)
 
 
-def mlp_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, meta: BlockMeta,
-                 ln_w, ln_b, w1, b1, w2, b2, residual: bool, want_bf16: bool):
+def mlp_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, meta: BlockMeta,
+                 ln_w, ln_b, w1, b1, w2, b2, residual: bool, want_bf16: bool, want_f32: bool = True):
     x, xn, mean, rstd, u, h = saved
     if dy16 is None:
         dy16 = K.cast_bf16(dy32)
@@ -180,10 +224,12 @@ def mlp_half_bwd(dy32: Tensor, dy16: Optional[Tensor], saved, meta: BlockMeta,
     du = K.gemm_nt(dy16, w2_t, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
     dw1, db1 = _dw_db(meta, du, xn, w1, b1)
     dxn = K.gemm_nt(du, w1_t, out_dtype=torch.bfloat16)
+    _join_side()
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
-    dx32, dx16, dg, db = K.layernorm_bwd(dxn, x, ln_w, mean, rstd, dres=dy32 if residual else None,
-                                         want_f32=True, want_bf16=want_bf16, dgamma=tg, dbeta=tb, accumulate=bg != 0.0)
+    dres = (dy32 if dy32 is not None else dy16) if residual else None
+    dx32, dx16, dg, db = K.layernorm_bwd(dxn, x, ln_w, mean, rstd, dres=dres,
+                                         want_f32=want_f32, want_bf16=want_bf16, dgamma=tg, dbeta=tb, accumulate=bg != 0.0)
     return dx32, dx16, [dg, db, dw1, db1, dw2, db2]
 
 
@@ -234,11 +280,16 @@ class EncoderStackFn(torch.autograd.Function):
         d32 = dy.to(torch.float32).contiguous().reshape(B * N, D)
         d16 = None
         grads: List[Optional[Tensor]] = [None] * len(params)
+        # GRAD_STREAM_BF16: the residual-stream gradient travels between the halves in bf16 only (it is a GEMM operand
+        # in bf16 anyway); the fp32 copy is produced once, at the bottom of the stack, for autograd.
+        bf16_stream = GRAD_STREAM_BF16
         for i in reversed(range(depth)):
             p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             sa, sm = saved[i]
-            d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True)
-            d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0)
+            d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True,
+                                        want_f32=not bf16_stream)
+            d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0,
+                                         want_f32=(not bf16_stream) or i == 0)
             grads[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = ga + gm
             saved[i] = None                                  # free this block's activations early
             if meta.sink is not None:
