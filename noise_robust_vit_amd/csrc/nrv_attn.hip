@@ -41,7 +41,7 @@ struct AttnParams {
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(ATT_THREADS, (NP <= 128 ? 4 : 2)) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;
     char* vimg = smem + NP * 128;
@@ -52,58 +52,72 @@ __global__ __launch_bounds__(ATT_THREADS, (NP <= 128 ? 4 : 2)) void attn_fwd_ker
     const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
     load_image<NP, false, ATT_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
     load_image<NP, true, ATT_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
-    __syncthreads();
 
     const int g = lane >> 4, qc = lane & 15;
     const float sc = p.scale * LOG2E;
     const int nqt = (N + 15) >> 4;
+    // the wave's first query fragments are fetched while the K/V images are still landing
+    bf16x8_t qf[2];
+    {
+        const int q0 = wave * 16 + qc;
+        const int qr0 = q0 < N ? q0 : N - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = load_frag_global(qbase + (long long)qr0 * ldq + ks * 32 + g * 8);
+    }
+    __syncthreads();
+
+    // Two passes over the keys keep the register footprint small (<= 128 VGPRs => two workgroups = 16 waves per CU,
+    // which is what hides the per-head load latency): pass 1 finds the row maximum, pass 2 recomputes the score
+    // tiles, exponentiates and feeds P.V.  The extra K.Q^T MFMAs are free -- this kernel is latency-, not MFMA-bound.
     for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + qc;
-        const int qr = q < N ? q : N - 1;
-        bf16x8_t qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
-
-        f32x4_t s[NP / 16];
-#pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt) {
-            s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) s[kt] = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[ks], s[kt]);
-        }
-        // softmax over keys (registers + lane groups); keys >= N masked
         float m = -INFINITY;
+#pragma unroll 2
+        for (int kt = 0; kt < NP / 16; ++kt) {
+            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt)
+            for (int ks = 0; ks < 2; ++ks) st = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[ks], st);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = kt * 16 + 4 * g + e;
-                const float v = key < N ? s[kt][e] * sc : -INFINITY;
-                s[kt][e] = v;
-                m = fmaxf(m, v);
+                m = fmaxf(m, key < N ? st[e] * sc : -INFINITY);
             }
+        }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(s[kt][e] - m);
-                s[kt][e] = pv;
-                l += pv;
-            }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
 
+        float l = 0.f;
         f32x4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
         for (int kk = 0; kk < NP / 32; ++kk) {
-            const bf16x8_t pf = pack_frag(s[2 * kk], s[2 * kk + 1]);
+            f32x4_t pt[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) st = mfma16(row_frag_img(kimg, kk * 32 + hf * 16, ks, lane), qf[ks], st);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kk * 32 + hf * 16 + 4 * g + e;
+                    const float pv = key < N ? __builtin_amdgcn_exp2f(st[e] * sc - m) : 0.f;
+                    pt[hf][e] = pv;
+                    l += pv;
+                }
+            }
+            const bf16x8_t pf = pack_frag(pt[0], pt[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag_vimg(vimg, kk * 32, dt, lane), pf, o[dt]);
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        // next tile's query fragments (if any) before the stores of this one
+        const int qn = (qt + ATT_WAVES) * 16 + qc;
+        if (qt + ATT_WAVES < nqt) {
+            const int qrn = qn < N ? qn : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[ks] = load_frag_global(qbase + (long long)qrn * ldq + ks * 32 + g * 8);
         }
         if (q < N) {
             const float inv = 1.0f / l;

@@ -74,6 +74,7 @@ struct GemmNTParams {
     int K;
     int tiles_n;
     int stagger;
+    int gn;                       // column-group width of the tile order (0 = plain row-major sweep)
     unsigned long long* stamps;   // debug only (NRV_GEMM_STAMPS=1): 4 x s_memrealtime + hw id per workgroup
     EpiParams e;
 };
@@ -242,7 +243,21 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
     const int wr = wave / C::WN, wc = wave - wr * C::WN;
 
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    // tile order: consecutive ids run concurrently on one XCD (xcd_remap).  With column groups of `gn` tiles the 32
+    // tiles an XCD holds at a time form an (32/gn) x gn block: fewer distinct A/B panels per round than a 1-D sweep,
+    // so more of the panel re-reads hit the XCD's 4 MiB L2 instead of the fabric.
+    int tm, tn;
+    if (p.gn > 0 && p.tiles_n > p.gn) {
+        const int tiles_m = gridDim.x / p.tiles_n;
+        const int gsize = tiles_m * p.gn;
+        const int grp = id / gsize, within = id - grp * gsize;
+        const int gw = (grp + 1) * p.gn <= p.tiles_n ? p.gn : p.tiles_n - grp * p.gn;     // width of this column group
+        tm = within / gw;
+        tn = grp * p.gn + (within - tm * gw);
+    } else {
+        tm = id / p.tiles_n;
+        tn = id - tm * p.tiles_n;
+    }
     const int m0 = tm * C::TBM, n0 = tn * C::TBN;
     const int M = p.e.M, N = p.e.N, K = p.K;
 
@@ -543,6 +558,8 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
     p.tiles_n = tiles_n;
     static const int stagger = [] { const char* e = getenv("NRV_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
     p.stagger = stagger;
+    static const int gn = [] { const char* e = getenv("NRV_GEMM_GN"); return e ? atoi(e) : 4; }();     // measured: 8192^3 1111 -> 1336 TFLOP/s
+    p.gn = gn;
     p.stamps = debug_stamp_buffer();
     hipLaunchKernelGGL((gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
     NRV_CHECK_LAUNCH();
@@ -577,6 +594,13 @@ int tn_splits(int64_t M, int64_t N, int64_t T) {
 
 }  // namespace
 
+// persistent kernel (nrv_gemm_persist.hip): returns -1000 when the shape is not for it
+int nrv_gemm_nt_persist_try(const void* A, long long lda, const void* B, long long ldb, void* C, int c_dtype, long long ldc,
+                            long long M, long long N, long long K, int epilogue_id, const float* bias,
+                            const void* aux, int aux_dtype, long long ld_aux, long long aux_row_mod,
+                            void* aux_out, long long ld_aux_out,
+                            long long out_group, long long out_group_stride, long long out_row_offset, hipStream_t s);
+
 extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
                                 void* C, int c_dtype, int64_t ldc,
                                 int64_t M, int64_t N, int64_t K,
@@ -606,6 +630,15 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     if (bias && !nrv_aligned16(bias)) return NRV_ERR_ALIGN;
     if (aux_out && (ld_aux_out < N || (ld_aux_out & 7) || !nrv_aligned16(aux_out))) return NRV_ERR_ALIGN;
 
+    // persistent kernel: correct (tests/test_kernels_gpu.py::test_gemm_nt_persistent_many_tiles) but measured slower than the
+    // one-tile-per-workgroup kernel on every ViT-B/16 shape: opt-in only
+    static const int persist = [] { const char* e = getenv("NRV_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+    if (persist) {
+        const int r = nrv_gemm_nt_persist_try(A, lda, B, ldb, C, c_dtype, ldc, M, N, K, epilogue_id, bias, aux, aux_dtype, ld_aux,
+                                              aux_row_mod, aux_out, ld_aux_out, out_group, out_group_stride, out_row_offset,
+                                              static_cast<hipStream_t>(stream));
+        if (r != -1000) return r;
+    }
     GemmNTParams p;
     p.A = static_cast<const bf16_t*>(A);
     p.B = static_cast<const bf16_t*>(B);

@@ -153,6 +153,49 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     assert (c - acc * uf.grad).abs().max().item() < 1e-5 * math.sqrt(K) * acc.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(50432, 768, 768), (25216, 1024, 4096), (12345 * 8, 384, 384)])
+def test_gemm_nt_persistent_many_tiles(dev, M, N, K):
+    """Shapes with many tiles per workgroup take the persistent kernel (3-stage LDS-DMA ring across tile boundaries,
+    deferred epilogue): every epilogue, M not a multiple of the 192-row tile, results against torch on the same operands."""
+    k = _k()
+    from noise_robust_vit_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU
+    A = rnd((M, K), dev, 26, 0.5)
+    B = rnd((N, K), dev, 27, 0.1)
+    bias = rnd((N,), dev, 28, 1.0, torch.float32)
+    acc = A.float() @ B.float().t()
+    tol = 1e-5 * math.sqrt(K)
+    c = k.gemm_nt(A, B, out_dtype=torch.float32)
+    assert rel_err(c, acc) < tol
+    c = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, bias=bias)
+    ref = acc + bias
+    assert ((c.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-3 * ref.abs().max()).all()
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    h = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=bias, aux_out=u)
+    ref_h = torch.nn.functional.gelu(ref)
+    assert ((h.float() - ref_h).abs() <= ref_h.abs() * 2 ** -8 + 1e-3).all()
+    assert ((u.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-3).all()
+    del h, ref_h
+    res = rnd((M, N), dev, 29, 1.0, torch.float32)
+    c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bias, aux=res)
+    assert rel_err(c, ref + res) < tol
+    del res
+    uf = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uf).sum().backward()
+    c = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
+    refd = acc * uf.grad
+    assert ((c.float() - refd).abs() <= refd.abs() * 2 ** -8 + 1e-3 * refd.abs().max()).all()
+    # class-token row remap through the persistent path
+    if M % 196 == 0:
+        G = 196
+        out = torch.zeros(M // G * (G + 1), N, dtype=torch.float32, device=dev)
+        pos = rnd((G + 1, N), dev, 30, 1.0, torch.float32)
+        k.gemm_nt(A, B, epilogue=EPI_BIAS_RESIDUAL, bias=bias, aux=pos[1:], aux_row_mod=G, out=out,
+                  out_group=G, out_group_stride=G + 1, out_row_offset=1)
+        r2 = (ref.reshape(M // G, G, N) + pos[1:])
+        assert rel_err(out.reshape(M // G, G + 1, N)[:, 1:], r2) < tol
+        assert out.reshape(M // G, G + 1, N)[:, 0].abs().max() == 0
+
+
 def test_gemm_nt_row_remap(dev):
     """class-token slot: result row m lands at (m // 196) * 197 + m % 196 + 1 (vit.py:341-342)."""
     k = _k()
