@@ -52,7 +52,8 @@ struct TileCfg {
 };
 using Cfg256 = TileCfg<2, 4, 8, 4>;
 using Cfg192 = TileCfg<2, 2, 6, 4>;
-using Cfg128 = TileCfg<2, 4, 4, 4>;      // 128x256 tile, 8 waves: finer tile granularity for N = 768 shapes
+using Cfg128 = TileCfg<2, 4, 4, 4>;
+using Cfg320 = TileCfg<2, 4, 10, 4>;     // 320x256 tile: 474 tiles for [50432 x 768] = 2 rounds of 256 CUs (256x256: 591 = 3 rounds)      // 128x256 tile, 8 waves: finer tile granularity for N = 768 shapes
 constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
 constexpr int EPI_PATCH_BYTES = 16 * EPI_ROW_F32 * 4;   // 4352 B per wave
 
@@ -122,7 +123,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
     const bool col_ok = ncol < e.N;                     // N % 8 == 0: a chunk is entirely inside or outside
     constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
     constexpr bool AUX32 = EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32;
-    constexpr int HALF = (MI + 1) / 2;
+    constexpr int HALF = MI > 8 ? (MI + 3) / 4 : (MI + 1) / 2;      // operand-prefetch depth, bounded by the register file
 
     f32x4_t bias4[V];
 #pragma unroll
@@ -365,6 +366,111 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT kernel, deep-ring variant: same 256x256 tile and wave layout, but the K dimension is streamed in 32-deep
+// half-steps through a ring of FOUR 32 KiB stages (16 KiB A + 16 KiB B) with counted vmcnt: three half-steps
+// (96 KiB) are in flight while the fourth is multiplied, instead of one 64 KiB stage.  The main loop of the 2-stage
+// kernel is LDS-DMA *latency* bound, so bytes in flight per CU is the lever.
+// LDS image: [256 rows][32 k] bf16 = 64-byte rows; chunk c (0..3) of row r sits at position c ^ G[(r >> 2) & 3],
+// G = {0, 3, 2, 1}: conflict-free ds_read_b128 for the fragment pattern (4 rows share a 256-byte bank row).
+// ---------------------------------------------------------------------------------------------
+constexpr int R_BK = 32, R_NST = 4, R_STAGE = 32768, R_B_OFF = 16384, R_LDS = R_NST * R_STAGE;
+
+__device__ __forceinline__ int ring_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
+
+__device__ __forceinline__ void wait_vmcnt_rt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int EPI, bool OUT_F32, bool AUX_F32>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ring_kernel(const GemmNTParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    if (p.gn > 0 && p.tiles_n > p.gn) {
+        const int tiles_m = gridDim.x / p.tiles_n;
+        const int gsize = tiles_m * p.gn;
+        const int grp = id / gsize, within = id - grp * gsize;
+        const int gw = (grp + 1) * p.gn <= p.tiles_n ? p.gn : p.tiles_n - grp * p.gn;
+        tm = within / gw;
+        tn = grp * p.gn + (within - tm * gw);
+    } else {
+        tm = id / p.tiles_n;
+        tn = id - tm * p.tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = p.e.M, N = p.e.N, K = p.K;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
+
+    // staging: DMA instruction i (0,1) of this wave fills rows 16*(8 i + wave) .. +15 of a half-step tile
+    unsigned st_a[2], st_b[2];
+    int st_k[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ring_swz(r);
+        st_k[i] = c * 8;
+        st_a[i] = (m0 + r < M) ? (unsigned)((long long)r * p.lda * 2) + c * 16 : NRV_OOB;
+        st_b[i] = (n0 + r < N) ? (unsigned)((long long)r * p.ldb * 2) + c * 16 : NRV_OOB;
+    }
+    const int nk = (K + R_BK - 1) / R_BK;
+    auto stage = [&](int s) {           // 4 DMA instructions per thread
+        char* base = smem + (s & (R_NST - 1)) * R_STAGE;
+        const int k0 = s * R_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool kok = (k0 + st_k[i]) < K;
+            dma16(ra, base + (i * 8 + wave) * 1024, (kok && st_a[i] != NRV_OOB) ? st_a[i] + k0 * 2 : NRV_OOB);
+            dma16(rb, base + R_B_OFF + (i * 8 + wave) * 1024, (kok && st_b[i] != NRV_OOB) ? st_b[i] + k0 * 2 : NRV_OOB);
+        }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // row = 16 q + fr  ->  (row >> 2) & 3 = (fr >> 2) & 3 (16 q is a multiple of 16)
+    const int a_rd = (wr * 128 + fr) * 64 + ((fg ^ ring_swz(fr)) << 4);
+    const int b_rd = R_B_OFF + (wc * 64 + fr) * 64 + ((fg ^ ring_swz(fr)) << 4);
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < R_NST - 1; ++s)
+        if (s < nk) stage(s);
+    for (int s = 0; s < nk; ++s) {
+        // younger than the DMA group of half-step s: the groups of s+1 and s+2 (4 instructions each) if they exist
+        const int younger = (s + 2 < nk ? 8 : (s + 1 < nk ? 4 : 0));
+        wait_vmcnt_rt(younger);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + R_NST - 1 < nk) stage(s + R_NST - 1);        // slot (s + 3) & 3 == (s - 1) & 3: read in the previous half-step
+        const char* sa = smem + (s & (R_NST - 1)) * R_STAGE;
+        bf16x8_t bfr[4], af[2];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bfr[ni] = lds_read_b128(sa + (b_rd + ni * 1024));
+        af[0] = lds_read_b128(sa + a_rd);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            if (mi + 1 < 8) af[(mi + 1) & 1] = lds_read_b128(sa + (a_rd + (mi + 1) * 1024));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bfr[ni], af[mi & 1], acc[mi][ni]);
+        }
+    }
+    __syncthreads();
+    epilogue<EPI, OUT_F32, AUX_F32, 8>(acc, smem, p.e, m0 + wr * 128, n0 + wc * 64, lane, wave);     // ring is idle: reuse it
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN kernel.  LDS tile image: [64 token rows][256 cols] bf16 = 512-byte rows; the 32-byte unit u
 // of row R is stored at unit position u ^ (R & 7): conflict-free ds_read_b64_tr_b16 (a 32-lane
 // half reads 8 rows x 32 bytes).  Both operands are read with the same transposed pattern, so the
@@ -566,17 +672,52 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
     return 0;
 }
 
+template <int EPI, bool OUT_F32, bool AUX_F32>
+int launch_nt_ring(GemmNTParams p, hipStream_t s) {
+    static int attr = set_lds(gemm_nt_ring_kernel<EPI, OUT_F32, AUX_F32>, R_LDS);
+    if (attr != 0) return attr;
+    const int tiles_m = (int)nrv_cdiv(p.e.M, BM), tiles_n = (int)nrv_cdiv(p.e.N, BN);
+    p.tiles_n = tiles_n;
+    static const int gn = [] { const char* e = getenv("NRV_GEMM_GN"); return e ? atoi(e) : 4; }();
+    p.gn = gn;
+    p.stagger = 0;
+    p.stamps = nullptr;
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), R_LDS, s, p);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
 // tile selection: NRV_GEMM_TILE=256|192 forces a configuration (bench / tests); default = heuristic
+int device_cus() {
+    static int n = [] {
+        int dev = 0, v = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+
 int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("NRV_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (forced == 256 || forced == 192 || forced == 128) return forced;
-    (void)M; (void)N; (void)K;
-    return 256;      // measured on the ViT-B/16 shapes: Cfg192 is LDS-DMA-bandwidth bound (2 x 40 KiB per K-step per CU)
+    if (forced == 256 || forced == 192 || forced == 128 || forced == 32 || forced == 320) return forced;
+    (void)K;
+    // One workgroup per CU: the kernel takes ceil(tiles / CUs) rounds of one tile time each.  Pick the tile height
+    // with the smaller rounds x rows product; e.g. [50432 x 768]: 591 tiles of 256 rows = 3 rounds, 474 tiles of 320
+    // rows = 2 rounds (measured 0.140 -> 0.121 ms with the fp32-residual epilogue).  The taller tile carries a ~3 %
+    // register-pressure penalty, so it must win by more than that.
+    const int64_t cus = device_cus();
+    const int64_t tn = nrv_cdiv(N, 256);
+    const double c256 = (double)nrv_cdiv(nrv_cdiv(M, 256) * tn, cus) * 256.0;
+    const double c320 = (double)nrv_cdiv(nrv_cdiv(M, 320) * tn, cus) * 320.0 * 1.03;
+    return c320 < c256 ? 320 : 256;
 }
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
     const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
+    if (tc == 32) return launch_nt_ring<EPI, OUT_F32, AUX_F32>(p, s);
+    if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32>(p, s);
     if (tc == 256) return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
     if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32>(p, s);
     return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32>(p, s);
