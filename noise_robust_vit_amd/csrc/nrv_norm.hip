@@ -14,7 +14,7 @@ namespace {
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / 64;
-constexpr int LN_BWD_BLOCKS = 512;
+constexpr int LN_BWD_BLOCKS = 1024;      // measured on [50432 x 768]: 512 -> 0.154 ms, 1024 -> 0.110 ms, 2048 -> 0.137 ms
 constexpr int COLSUM_ROWCHUNKS = 128;
 
 template <bool F32>

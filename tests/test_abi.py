@@ -44,7 +44,7 @@ def test_loader_sets_prototypes_and_reports_errors(lib_path):
     with pytest.raises(_lib.NrvError):
         _lib.check(-4, "demo")
     assert lib.nrv_gemm_tn_workspace(3072, 768, 50432) == 7 * 3072 * 768 * 4 + 7 * 3072 * 4     # 36 tiles -> 7 splits (+ bias slabs)
-    assert lib.nrv_layernorm_bwd_workspace(50432, 768) == 512 * 2 * 768 * 4
+    assert lib.nrv_layernorm_bwd_workspace(50432, 768) == 1024 * 2 * 768 * 4
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):
