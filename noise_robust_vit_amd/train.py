@@ -19,6 +19,7 @@ import math
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -36,6 +37,17 @@ def warmup_cosine_lr(step: int, base_lr: float, warmup_steps: int, cosine_steps:
     return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * t / cosine_steps)) / 2.0
 
 
+def cutmix_box(height: int, width: int, lam: float, rng: "np.random.Generator"):
+    """Random box covering a (1 - lam) fraction of the image, clipped to it (CutMix; the reference's `utils.rand_bbox`,
+    utils.py:1006-1022, which indexes dim 2 then dim 3 of the batch).  Returns (a1, b1, a2, b2): rows a1:a2, cols b1:b2."""
+    ratio = math.sqrt(max(0.0, 1.0 - lam))
+    cut_a, cut_b = int(height * ratio), int(width * ratio)
+    ca, cb = int(rng.integers(height)), int(rng.integers(width))
+    a1, a2 = max(ca - cut_a // 2, 0), min(ca + cut_a // 2, height)
+    b1, b2 = max(cb - cut_b // 2, 0), min(cb + cut_b // 2, width)
+    return a1, b1, a2, b2
+
+
 @dataclass
 class TrainConfig:
     lr: float = 5e-4
@@ -45,6 +57,9 @@ class TrainConfig:
     noise_std: float = 0.0
     warmup_steps: int = 0
     cosine_steps: int = 0
+    cutmix_prob: float = 0.0       # CIFAR100.py:119-137
+    cutmix_beta: float = 1.0
+    seed: int = 0
 
 
 class Trainer:
@@ -58,6 +73,7 @@ class Trainer:
         self.opt = torch.optim.AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay, eps=1e-8, betas=(0.9, 0.999),
                                      fused=fused)
         self.step_idx = 0
+        self.rng = np.random.default_rng(cfg.seed)
 
     def loss_fn(self, logits: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         return F.cross_entropy(logits, y, label_smoothing=self.cfg.label_smoothing)
@@ -67,8 +83,20 @@ class Trainer:
             x = x + torch.randn_like(x) * self.cfg.noise_std          # nowak.py:153
         if self.reducer is not None:
             self.reducer.begin_step()
-        logits = self.model(x)
-        loss = self.loss_fn(logits, y)
+        c = self.cfg
+        if c.cutmix_prob > 0.0 and self.rng.random() < c.cutmix_prob:
+            # CutMix as in the reference harness (CIFAR100.py:119-137): paste a box from a permuted batch, mix the losses
+            perm = torch.randperm(x.shape[0], device=x.device)
+            lam = float(self.rng.beta(c.cutmix_beta, c.cutmix_beta))
+            a1, b1, a2, b2 = cutmix_box(x.shape[2], x.shape[3], lam, self.rng)
+            x = x.clone()
+            x[:, :, a1:a2, b1:b2] = x[perm, :, a1:a2, b1:b2]
+            lam = 1.0 - (a2 - a1) * (b2 - b1) / float(x.shape[-1] * x.shape[-2])      # exact pixel ratio
+            logits = self.model(x)
+            loss = self.loss_fn(logits, y) * lam + self.loss_fn(logits, y[perm]) * (1.0 - lam)
+        else:
+            logits = self.model(x)
+            loss = self.loss_fn(logits, y)
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish_step()          # waits for the overlapped all-reduces; grads are now rank-averaged

@@ -24,7 +24,7 @@ from ._lib import PATCH_CP1P2, NrvError
 from .encoder import AttnHalfFn, BlockMeta, EncoderStackFn, MlpHalfFn, PatchEmbedFn
 from .simple_vit import SinkhornAttention
 
-__all__ = ["VisionTransformer", "Encoder", "EncoderBlock", "MLPBlock", "MultiheadAttention",
+__all__ = ["VisionTransformer", "Encoder", "EncoderBlock", "MLPBlock", "MultiheadAttention", "interpolate_embeddings",
            "vit_s_16", "vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32", "vit_h_14"]
 
 
@@ -235,6 +235,31 @@ class VisionTransformer(nn.Module):
         ln = self.encoder.ln
         cls = torch.nn.functional.layer_norm(cls, (cls.shape[-1],), ln.weight, ln.bias, ln.eps)
         return self.heads(cls)
+
+
+def interpolate_embeddings(image_size: int, patch_size: int, model_state, interpolation_mode: str = "bicubic",
+                           reset_heads: bool = False):
+    """Resize `encoder.pos_embedding` of a checkpoint to a new image size (same contract as vit.py:522-603): the class
+    token's position is kept, the patch positions are viewed as a square grid and resampled (align_corners=True).
+    Updates `model_state` in place and returns it (a copy without `heads.*` when `reset_heads`)."""
+    pos = model_state["encoder.pos_embedding"]
+    if pos.dim() != 3 or pos.shape[0] != 1:
+        raise ValueError(f"Unexpected position embedding shape: {pos.shape}")
+    hidden = pos.shape[2]
+    old_tokens = pos.shape[1] - 1
+    new_side = image_size // patch_size
+    if new_side * new_side == old_tokens:
+        return model_state
+    old_side = math.isqrt(old_tokens)
+    if old_side * old_side != old_tokens:
+        raise ValueError(f"seq_length is not a perfect square! Instead got seq_length = {old_tokens}")
+    grid = pos[:, 1:, :].transpose(1, 2).reshape(1, hidden, old_side, old_side)
+    grid = nn.functional.interpolate(grid, size=new_side, mode=interpolation_mode, align_corners=True)
+    grid = grid.reshape(1, hidden, new_side * new_side).transpose(1, 2)
+    model_state["encoder.pos_embedding"] = torch.cat([pos[:, :1, :], grid], dim=1)
+    if reset_heads:
+        return OrderedDict((k, v) for k, v in model_state.items() if not k.startswith("heads"))
+    return model_state
 
 
 def _vision_transformer(patch_size: int, num_layers: int, num_heads: int, hidden_dim: int, mlp_dim: int,

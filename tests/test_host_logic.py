@@ -134,3 +134,54 @@ def test_robust_flag_is_plumbed_not_substituted():
     m = SimpleViT(image_size=32, patch_size=16, num_classes=10, dim=64, depth=1, heads=1, mlp_dim=128, robust=True)
     assert isinstance(m.transformer.layers[0][0].attend, SinkhornAttention)
     assert m.transformer._meta.robust and m.transformer.layers[0][0]._meta.robust
+
+
+def test_interpolate_embeddings_matches_direct_resample():
+    """vit.py:522-603: class-token position untouched, the 2x2 patch grid of a 32-px checkpoint resampled to 4x4."""
+    from collections import OrderedDict
+    from noise_robust_vit_amd.vit import VisionTransformer, interpolate_embeddings
+    src = VisionTransformer(image_size=32, patch_size=16, num_layers=1, num_heads=1, hidden_dim=64, mlp_dim=128, num_classes=3)
+    sd = OrderedDict((k, v.clone()) for k, v in src.state_dict().items())
+    pos = sd["encoder.pos_embedding"].clone()
+    out = interpolate_embeddings(64, 16, sd, reset_heads=True)
+    assert not any(k.startswith("heads") for k in out) and "encoder.ln.weight" in out
+    new = out["encoder.pos_embedding"]
+    assert new.shape == (1, 17, 64) and torch.equal(new[:, 0], pos[:, 0])
+    grid = pos[0, 1:].t().reshape(1, 64, 2, 2)
+    ref = torch.nn.functional.interpolate(grid, size=4, mode="bicubic", align_corners=True).reshape(64, 16).t()
+    assert torch.allclose(new[0, 1:], ref, atol=1e-6)
+    # corners are preserved with align_corners=True
+    assert torch.allclose(new[0, 1], pos[0, 1], atol=1e-6) and torch.allclose(new[0, 16], pos[0, 4], atol=1e-6)
+    dst = VisionTransformer(image_size=64, patch_size=16, num_layers=1, num_heads=1, hidden_dim=64, mlp_dim=128, num_classes=3)
+    missing = dst.load_state_dict(out, strict=False)
+    assert set(missing.missing_keys) == {"heads.head.weight", "heads.head.bias"} and not missing.unexpected_keys
+    # same size: state returned untouched
+    same = interpolate_embeddings(32, 16, OrderedDict(src.state_dict()))
+    assert same["encoder.pos_embedding"].shape == (1, 5, 64)
+
+
+def test_cutmix_box_and_trainer_loss_mix():
+    """CIFAR100.py:119-137: box area ~ (1 - lam), loss = lam CE(y) + (1 - lam) CE(y[perm]) with lam = exact pixel ratio."""
+    import numpy as np
+    from noise_robust_vit_amd.train import TrainConfig, Trainer, cutmix_box
+    rng = np.random.default_rng(0)
+    for lam in (0.1, 0.5, 0.9):
+        for _ in range(20):
+            a1, b1, a2, b2 = cutmix_box(224, 224, lam, rng)
+            assert 0 <= a1 <= a2 <= 224 and 0 <= b1 <= b2 <= 224
+            assert (a2 - a1) * (b2 - b1) <= (1 - lam) * 224 * 224 + 1
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 8 * 8, 5))
+    x = torch.randn(6, 3, 8, 8); y = torch.randint(0, 5, (6,))
+    tr = Trainer(net, TrainConfig(cutmix_prob=1.0, seed=3, grad_max_norm=0.0))
+    torch.manual_seed(11)
+    loss = tr.forward_backward(x, y)
+    # replay the same random decisions
+    rng = np.random.default_rng(3); assert rng.random() < 1.0
+    torch.manual_seed(11); perm = torch.randperm(6)
+    lam = float(rng.beta(1.0, 1.0)); a1, b1, a2, b2 = cutmix_box(8, 8, lam, rng)
+    xm = x.clone(); xm[:, :, a1:a2, b1:b2] = x[perm, :, a1:a2, b1:b2]
+    lam = 1.0 - (a2 - a1) * (b2 - b1) / 64.0
+    out = net(xm)
+    ce = lambda t: torch.nn.functional.cross_entropy(out, t, label_smoothing=0.1)
+    assert abs(loss.item() - (ce(y) * lam + ce(y[perm]) * (1 - lam)).item()) < 1e-6
