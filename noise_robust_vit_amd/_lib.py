@@ -13,7 +13,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRV_LIB_PATH: developer override used to A/B kernel variants (tools/); the shipped path is the in-tree library
-LIB_PATH = os.environ.get("NRV_LIB_PATH") or os.path.join(_HERE, "lib", "libnrv_hip.so")
+_DEFAULT_LIB = os.path.join(_HERE, "lib", "libnrv_hip.so")
+LIB_PATH = os.environ.get("NRV_LIB_PATH") or _DEFAULT_LIB
 
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
@@ -71,6 +72,15 @@ def load() -> ctypes.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        if not os.path.exists(LIB_PATH) and LIB_PATH == _DEFAULT_LIB and not os.environ.get("NRV_NO_AUTOBUILD"):
+            # the in-tree library is a build product (git-ignored): compile it if the toolchain is here.  This is
+            # the same HIP code path, not a fallback; without hipcc the error below is raised.
+            try:
+                from . import build as _build
+                _build.build()
+            except Exception as e:        # noqa: BLE001 -- reported below
+                raise NrvError(f"{LIB_PATH} is missing and building it failed ({e}); the HIP kernels are the product "
+                               "and there is no fallback path") from e
         if not os.path.exists(LIB_PATH):
             raise NrvError(
                 f"{LIB_PATH} not found: the HIP kernels are the product and there is no fallback path. "
