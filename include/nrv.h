@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 2
+#define NRV_ABI_VERSION 3
 
 /* dtype codes */
 #define NRV_F32 0
@@ -46,9 +46,9 @@ extern "C" {
 /* GEMM epilogues (fused into the MFMA kernel's store phase) */
 #define NRV_EPI_NONE 0           /* C = acc                                                     */
 #define NRV_EPI_BIAS 1           /* C = acc + bias[n]                                           */
-#define NRV_EPI_BIAS_GELU 2      /* u = acc + bias[n]; aux_out = bf16(u) (optional); C = gelu_erf(u) */
+#define NRV_EPI_BIAS_GELU 2      /* u = acc + bias[n]; aux_out = bf16(gelu_erf'(u)) (optional); C = gelu_erf(u) */
 #define NRV_EPI_BIAS_RESIDUAL 3  /* C = acc + bias[n] (bias optional) + aux[m % aux_row_mod][n] */
-#define NRV_EPI_DGELU 4          /* C = acc * gelu_erf'(aux[m][n])           (aux = saved u, bf16) */
+#define NRV_EPI_DGELU 4          /* C = acc * aux[m][n]     (aux = the bf16 gelu' saved by NRV_EPI_BIAS_GELU) */
 
 int nrv_abi_version(void);
 const char* nrv_error_string(int code);
@@ -87,7 +87,8 @@ int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const flo
  *   aux: epilogue operand [*, N] of aux_dtype with ld_aux; aux_row_mod > 0 makes the aux row
  *        index m % aux_row_mod (broadcast of a [tokens, dim] positional table over the batch,
  *        simple_vit.py:142-143); 0 means row m.
- *   aux_out: optional bf16 [M,N] (ldc_aux) receiving the pre-activation for NRV_EPI_BIAS_GELU.
+ *   aux_out: optional bf16 [M,N] (ldc_aux) receiving gelu'(pre-activation) for NRV_EPI_BIAS_GELU: the backward's
+ *        NRV_EPI_DGELU epilogue is then one multiply, no second erf/exp evaluation.
  *   Output row remap (class-token slot, vit.py:341-342): if out_group > 0 the result row m is
  *   stored at row (m / out_group) * out_group_stride + (m % out_group) + out_row_offset of C
  *   (and of aux, when aux_row_mod == 0).

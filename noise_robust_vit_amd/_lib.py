@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NRV_LIB_PATH") or _DEFAULT_LIB
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {

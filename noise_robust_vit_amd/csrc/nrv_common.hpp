@@ -69,6 +69,12 @@ __device__ __forceinline__ float gelu_fwd(float u) {
     gelu_parts(u, Phi, phi);
     return u * Phi;
 }
+__device__ __forceinline__ void gelu_both(float u, float& g, float& dg) {
+    float Phi, phi;
+    gelu_parts(u, Phi, phi);
+    g = u * Phi;
+    dg = fmaf(u, phi, Phi);
+}
 __device__ __forceinline__ float gelu_grad(float u) {
     float Phi, phi;
     gelu_parts(u, Phi, phi);

@@ -186,10 +186,12 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
                         for (int v = 0; v < V; ++v) {
                             f32x4_t x = val[v] + bias4[v];
                             if (EPI == NRV_EPI_BIAS_GELU) {
-                                pku[2 * v] = pack_bf16x2(x[0], x[1]);
-                                pku[2 * v + 1] = pack_bf16x2(x[2], x[3]);
+                                // one erf/exp evaluation gives both gelu(u) (the output) and gelu'(u) (saved for the backward)
+                                f32x4_t dg;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) x[j] = gelu_fwd(x[j]);
+                                for (int j = 0; j < 4; ++j) { float gv, dv; gelu_both(x[j], gv, dv); x[j] = gv; dg[j] = dv; }
+                                pku[2 * v] = pack_bf16x2(dg[0], dg[1]);
+                                pku[2 * v + 1] = pack_bf16x2(dg[2], dg[3]);
                             }
                             if (EPI == NRV_EPI_BIAS_RESIDUAL) {
                                 if (AUX32) {
@@ -202,8 +204,8 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
                             }
                             if (EPI == NRV_EPI_DGELU) {
                                 const u32x2_t a = aux16[mh][i][v];
-                                x[0] *= gelu_grad(bf16lo_to_f32(a[0])); x[1] *= gelu_grad(bf16hi_to_f32(a[0]));
-                                x[2] *= gelu_grad(bf16lo_to_f32(a[1])); x[3] *= gelu_grad(bf16hi_to_f32(a[1]));
+                                x[0] *= bf16lo_to_f32(a[0]); x[1] *= bf16hi_to_f32(a[0]);
+                                x[2] *= bf16lo_to_f32(a[1]); x[3] *= bf16hi_to_f32(a[1]);
                             }
                             if (OUT_F32) {
                                 *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.C) + orow * e.ldc + ncol + 4 * v) = x;

@@ -259,10 +259,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void gemm_nt_persist_kernel(const PPa
             for (int v = 0; v < T::V; ++v) {
                 f32x4_t x = *reinterpret_cast<const f32x4_t*>(stg + r * P_ROW_F32 + rcol * T::CW + 4 * v) + b4[v];
                 if (EPI == NRV_EPI_BIAS_GELU) {
-                    pku[2 * v] = pack_bf16x2(x[0], x[1]);
-                    pku[2 * v + 1] = pack_bf16x2(x[2], x[3]);
+                    f32x4_t dg;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) x[j] = gelu_fwd(x[j]);
+                    for (int j = 0; j < 4; ++j) { float gv, dv; gelu_both(x[j], gv, dv); x[j] = gv; dg[j] = dv; }
+                    pku[2 * v] = pack_bf16x2(dg[0], dg[1]);
+                    pku[2 * v + 1] = pack_bf16x2(dg[2], dg[3]);
                 }
                 if (EPI == NRV_EPI_BIAS_RESIDUAL) {
                     if (T::AUX32) {
@@ -275,8 +276,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void gemm_nt_persist_kernel(const PPa
                 }
                 if (EPI == NRV_EPI_DGELU) {
                     const u32x2_t q = aux16[mi][i][v];
-                    x[0] *= gelu_grad(bf16lo_to_f32(q[0])); x[1] *= gelu_grad(bf16hi_to_f32(q[0]));
-                    x[2] *= gelu_grad(bf16lo_to_f32(q[1])); x[3] *= gelu_grad(bf16hi_to_f32(q[1]));
+                    x[0] *= bf16lo_to_f32(q[0]); x[1] *= bf16hi_to_f32(q[0]);
+                    x[2] *= bf16lo_to_f32(q[1]); x[3] *= bf16hi_to_f32(q[1]);
                 }
                 if (OUT_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), rc,

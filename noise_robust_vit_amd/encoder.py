@@ -204,7 +204,7 @@ def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residua
     w1_b, _ = WEIGHTS.get(w1, True)
     w2_b, _ = WEIGHTS.get(w2, True)
     T = x.shape[0]
-    u = torch.empty(T, w1.shape[0], dtype=torch.bfloat16, device=x.device)
+    u = torch.empty(T, w1.shape[0], dtype=torch.bfloat16, device=x.device)     # receives gelu'(pre-activation)
     h = K.gemm_nt(xn, w1_b, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=b1, aux_out=u)
     if residual:
         y = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=b2, aux=x)

@@ -135,7 +135,9 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     h = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_GELU, bias=bias, aux_out=u)
     ref_h = torch.nn.functional.gelu(acc + bias)            # erf form
     assert (h - ref_h).abs().max().item() < 3e-6 * (1 + ref_h.abs().max().item())
-    assert ((u.float() - (acc + bias)).abs() <= (acc + bias).abs() * 2 ** -8 + 1e-5).all()
+    pre = (acc + bias).requires_grad_(True)
+    torch.nn.functional.gelu(pre).sum().backward()          # pre.grad = gelu'(pre), what aux_out must hold (bf16)
+    assert ((u.float() - pre.grad).abs() <= pre.grad.abs() * 2 ** -8 + 1e-5).all()
     # bias + residual, fp32 stream
     res = rnd((M, N), dev, 23, 1.0, torch.float32)
     c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bias, aux=res)
@@ -145,12 +147,10 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, aux=tab, aux_row_mod=50)
     idx = torch.arange(M, device=dev) % 50
     assert rel_err(c, acc + tab.float()[idx]) < 1e-5 * math.sqrt(K)
-    # dGELU
+    # backward epilogue: multiply by the saved derivative
     uu = rnd((M, N), dev, 25, 1.5)
     c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_DGELU, aux=uu)
-    uf = uu.float().requires_grad_(True)
-    torch.nn.functional.gelu(uf).sum().backward()
-    assert (c - acc * uf.grad).abs().max().item() < 1e-5 * math.sqrt(K) * acc.abs().max().item()
+    assert (c - acc * uu.float()).abs().max().item() < 1e-5 * math.sqrt(K) * acc.abs().max().item()
 
 
 @pytest.mark.parametrize("M,N,K", [(50432, 768, 768), (25216, 1024, 4096), (12345 * 8, 384, 384)])
@@ -173,16 +173,16 @@ def test_gemm_nt_persistent_many_tiles(dev, M, N, K):
     h = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=bias, aux_out=u)
     ref_h = torch.nn.functional.gelu(ref)
     assert ((h.float() - ref_h).abs() <= ref_h.abs() * 2 ** -8 + 1e-3).all()
-    assert ((u.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-3).all()
-    del h, ref_h
+    pre = ref.clone().requires_grad_(True)
+    torch.nn.functional.gelu(pre).sum().backward()
+    assert ((u.float() - pre.grad).abs() <= pre.grad.abs() * 2 ** -8 + 1e-3).all()
+    del h, ref_h, pre
     res = rnd((M, N), dev, 29, 1.0, torch.float32)
     c = k.gemm_nt(A, B, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bias, aux=res)
     assert rel_err(c, ref + res) < tol
     del res
-    uf = u.float().requires_grad_(True)
-    torch.nn.functional.gelu(uf).sum().backward()
     c = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
-    refd = acc * uf.grad
+    refd = acc * u.float()
     assert ((c.float() - refd).abs() <= refd.abs() * 2 ** -8 + 1e-3 * refd.abs().max()).all()
     # class-token row remap through the persistent path
     if M % 196 == 0:
