@@ -53,6 +53,19 @@ def build_model(arch: str, num_classes: int = 1000):
     return m
 
 
+def pmc_traffic(kernel_class: str):
+    """HBM/fabric bytes per launch of a kernel class from the committed PMC passes of this same command
+    (profiles/r01_traffic_per_launch.json, produced by tools/traffic_from_pmc.py from separate `rocprofv3 --pmc FETCH_SIZE`
+    and `--pmc WRITE_SIZE` runs of bench.py, with the gfx950 FETCH_SIZE x2 correction).  A profiler cannot run inside the
+    timed process, so the number is read from that file; null when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_per_launch.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["per_launch_bytes"][kernel_class]["total"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(arch: str, seconds_budget: float = 15.0):
     """Reference-algorithm CPU path (oracle port: fp32 forward + autograd backward + CE) on the host cores."""
     from oracle import simple_vit_oracle as SO
@@ -201,7 +214,7 @@ def main():
             ach = gnt["flops"] / (gnt["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (MFMA bf16 NT GEMM, all epilogues)",
                                "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_nt"),
                                "launches_per_step": gnt["launches"] // 2,
                                "avg_launch_ms": round(gnt["ms"] / gnt["launches"], 4),
                                "alg_flop_per_launch": round(gnt["flops"] / gnt["launches"]),

@@ -191,21 +191,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 }
 
 // out[c] = beta * out[c] + sum_p partial[p][c]  (fixed summation order)
-__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ partial, int P, int ncols,
-                                                           float* __restrict__ out0, float* __restrict__ out1, int split_col,
-                                                           float beta) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+// 16 columns x 64 row-lanes per workgroup: with ~1000 partial rows and ~1500 columns this gives ~100 workgroups and 16
+// loads per thread (a 64-column x 16-lane layout left the kernel on 24 CUs with 64 dependent loads per thread: 20 us).
+constexpr int RR_COLS = 16, RR_LANES = 64;
+__global__ __launch_bounds__(RR_COLS * RR_LANES) void reduce_rows_kernel(const float* __restrict__ partial, int P, int ncols,
+                                                                         float* __restrict__ out0, float* __restrict__ out1,
+                                                                         int split_col, float beta) {
+    __shared__ float red[RR_LANES][RR_COLS + 1];
+    const int cl = threadIdx.x % RR_COLS, rl = threadIdx.x / RR_COLS;
+    const int c = blockIdx.x * RR_COLS + cl;
     float s = 0.f;
     if (c < ncols)
-        for (int p = rl; p < P; p += 16) s += partial[(long long)p * ncols + c];
+        for (int p = rl; p < P; p += RR_LANES) s += partial[(long long)p * ncols + c];
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < ncols) {
         float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][cl];
+#pragma unroll 8
+        for (int k = 0; k < RR_LANES; ++k) t += red[k][cl];
         float* dst = c < split_col ? out0 + c : out1 + (c - split_col);
         *dst = beta != 0.f ? beta * (*dst) + t : t;
     }
@@ -308,7 +311,7 @@ extern "C" int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype
 #undef NRV_LN_BWD
     NRV_CHECK_LAUNCH();
     // partial rows are [grid*2][dim] with (block, pass) interleaved: view as [grid][2*dim]
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * dim + 63) / 64), dim3(1024), 0, s,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * dim + RR_COLS - 1) / RR_COLS), dim3(RR_COLS * RR_LANES), 0, s,
                        partial, grid, 2 * dim, dgamma, dbeta, dim, accumulate ? 1.0f : 0.0f);
     NRV_CHECK_LAUNCH();
     return 0;
@@ -334,7 +337,7 @@ extern "C" int nrv_colsum_bf16(const void* X, int64_t ld, float* out, int64_t T,
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nrv_cdiv(N, 512), (unsigned)chunks), dim3(256), 0, s,
                        static_cast<const bf16_t*>(X), (long long)ld, partial, (long long)T, (int)N, (int)rpc);
     NRV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)nrv_cdiv(N, 64)), dim3(1024), 0, s,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)nrv_cdiv(N, RR_COLS)), dim3(RR_COLS * RR_LANES), 0, s,
                        partial, chunks, (int)N, out, out, (int)N, beta);
     NRV_CHECK_LAUNCH();
     return 0;
