@@ -17,6 +17,10 @@
 //   dq kernel : wave owns 16 queries, sweeps keys  -> dQ, and delta = rowsum(dO * O)
 //   dkv kernel: wave owns 16 keys,   sweeps queries -> dK, dV
 // P is recomputed from q, k and the saved log-sum-exp.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "nrv_attn_common.hpp"
 
 namespace {
@@ -35,6 +39,8 @@ struct AttnParams {
     float* delta;          // [B, H, N]
     int B, N, H;
     float scale;
+    unsigned long long* stamps;   // dev only (NRV_ATTN_DBG=3)
+    int dbg;               // dev only (NRV_ATTN_DBG bit mask): 1 = skip compute, 2 = skip the per-head loads after the first, 4 = stamps
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -125,6 +131,192 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnPara
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, o[dt] * inv);
             if (g == 0) p.lse[((long long)b * p.H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, 4 fat waves: one workgroup of 4 waves (one per SIMD, <= 256 VGPRs) per (batch, head), TWO workgroups per CU.
+//   * K and V images arrive by 16-byte LDS-DMA (swizzles applied to the per-lane SOURCE address, the DMA destination is
+//     lane-linear; rows >= N read as zero through the buffer descriptor).  While one workgroup of a CU waits for its
+//     images the other one computes: the per-head HBM latency is hidden by the co-resident workgroup, not by a
+//     software pipeline.
+//   * A wave owns TWO 16-query tiles (32 queries) at a time: every K / V^T fragment read from LDS feeds both tiles (half
+//     the LDS traffic) and the in-order wave has two independent MFMA -> softmax -> MFMA chains.
+//   * Single pass: all N/16 score tiles of both query tiles stay in registers, K.Q^T is computed once; K fragments run
+//     3 key tiles ahead of their MFMAs, V^T fragments one 32-key step ahead (s_memtime stamps: with one tile ahead the
+//     S phase is 2x slower; with lgkmcnt(0) after every read, as in the thin-wave kernel above, the whole head is).
+// Measured on MI355X (ViT-B/16, B = 256, N = 197): see DESIGN.md.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATF_THREADS = 256;
+constexpr int ATF_WAVES = 4;
+
+// NT = number of 16-key tiles = image rows / 16.  N = 196 / 197 => NT = 13: 2 x 13 x 2 KiB = 53,248 B of LDS, THREE
+// workgroups per CU (with rows padded to 32 it would be 57,344 B and two).
+template <int NT>
+__global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = NT * 16;                // image rows
+    constexpr int IMG = NP * 128;              // one image
+    constexpr int NS = (NT + 1) / 2;           // 32-key steps of P.V (the last one is half empty when NT is odd)
+    constexpr int NJ = 2 * NP / 8;             // DMA instructions (1 KiB = 8 rows each): K rows then V rows
+    constexpr int JPW = NJ / ATF_WAVES;        // = NT
+    constexpr int MT = (NT == 13 || NT == 14) ? 1 : 2;   // trailing key tiles that can hold padding rows (launch_fwd_fat rounds other counts up to even)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, H = p.H;
+    const long long ldq = 3ll * H * DH;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const bf16_t* hb = p.qkv + (long long)b * N * ldq + h * DH;
+    const int g = lane >> 4, qc = lane & 15;
+    const float sc = p.scale * LOG2E;
+    const char* kimg = smem;
+    const char* vimg = smem + IMG;
+
+    // first pair's query fragments, then the image DMAs (vmcnt is in order: the fragments complete first)
+    const int npairs = (N + 31) >> 5;
+    bf16x8_t qf[2][2];
+    auto load_q = [&](int pair) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = pair * 32 + t * 16 + qc;
+            const int qr = q < N ? q : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[t][ks] = load_frag_global(hb + (long long)qr * ldq + ks * 32 + g * 8);
+        }
+    };
+    if (wave < npairs) load_q(wave);
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(hb, 0x7fffffffull);
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) {
+            const int j = wave * JPW + i;
+            const bool isv = j >= NP / 8;
+            const int r = 8 * (isv ? j - NP / 8 : j) + (lane >> 3);
+            const int pos = lane & 7;
+            const int c = isv ? ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1)) : (pos ^ ((r >> 1) & 7));
+            const unsigned vo = (r < N) ? (unsigned)(r * ldq * 2 + c * 16 + (isv ? 2 : 1) * H * DH * 2) : NRV_OOB;
+            dma16(rs, smem + j * 1024, vo);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): through the builtin so that hipcc's own counting stays exact
+    asm volatile("" ::: "memory");
+    __syncthreads();
+
+    const bf16x4_t zero4 = {0, 0, 0, 0};
+    // V^T fragment of 32-key step kk, feature tile dt; the upper 16 keys of the last step do not exist when NT is odd
+    auto v_frag = [&](int kk, int dt) {
+        const int q = (lane & 15) >> 2, pp = lane & 3;
+        const int r0 = kk * 32 + 4 * g + q;
+        const bf16x4_t lo = lds_read_tr16_b64(vimg + r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + pp * 8);
+        if (2 * kk + 1 >= NT) return cat4(lo, zero4);
+        return cat4(lo, lds_read_tr16_b64(vimg + (r0 + 16) * 128 + ((dt ^ (((r0 + 16) >> 1) & 3)) << 5) + pp * 8));
+    };
+    const int d_lane = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;       // first feature of the lane's 8 within a 32-feature pair
+    for (int pair = wave; pair < npairs; pair += ATF_WAVES) {
+        // ---- S^T = K Q^T for every key tile, both query tiles
+        f32x4_t st[2][NT];
+        constexpr int KD = NT < 4 ? NT : 4;                        // fragment ring: 3 key tiles (12 MFMAs) ahead of their use
+        bf16x8_t kf[KD][2];
+#pragma unroll
+        for (int j = 0; j < KD - 1; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[j][ks] = row_frag_img(kimg, j * 16, ks, lane);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt + KD - 1 < NT) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) kf[(kt + KD - 1) % KD][ks] = row_frag_img(kimg, (kt + KD - 1) * 16, ks, lane);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a = mfma16(kf[kt % KD][ks], qf[t][ks], a);
+                st[t][kt] = a;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next pair's query fragments and the first V^T fragments are in flight during the softmax arithmetic
+        const int q0 = pair * 32 + qc;
+        if (pair + ATF_WAVES < npairs) load_q(pair + ATF_WAVES);
+        bf16x8_t vf[2][4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf[0][dt] = v_frag(0, dt);
+        // ---- softmax over the keys (a lane holds 4 keys of each tile for one query; 4 lanes share a query)
+        float m[2], l[2];
+        bf16x8_t pf[2][NS];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float mm = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (kt >= NT - MT) mm = fmaxf(mm, (kt * 16 + 4 * g + e < N) ? st[t][kt][e] : -INFINITY);
+                    else mm = fmaxf(mm, st[t][kt][e]);
+                }
+            }
+            mm = fmaxf(mm, __shfl_xor(mm, 16, 64));
+            mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
+            mm *= sc;                                               // sc > 0: max commutes with the scaling
+            float ll = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pv = __builtin_amdgcn_exp2f(fmaf(st[t][kt][e], sc, -mm));
+                    if (kt >= NT - MT) pv = (kt * 16 + 4 * g + e < N) ? pv : 0.f;
+                    st[t][kt][e] = pv;
+                    ll += pv;
+                }
+                if (kt & 1) pf[t][kt >> 1] = pack_frag(st[t][kt - 1], st[t][kt]);
+                else if (kt == NT - 1) pf[t][kt >> 1] = pack_frag(st[t][kt], f32x4_t{0.f, 0.f, 0.f, 0.f});
+            }
+            ll += __shfl_xor(ll, 16, 64);
+            ll += __shfl_xor(ll, 32, 64);
+            m[t] = mm;
+            l[t] = ll;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T = V^T P^T, V^T fragments one step ahead
+        f32x4_t o[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NS; ++kk) {
+            if (kk + 1 < NS) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vf[(kk + 1) & 1][dt] = v_frag(kk + 1, dt);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) o[t][dt] = mfma16(vf[kk & 1][dt], pf[t][kk], o[t][dt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // normalise, pack, and regroup through v_permlane16_swap: lane (q, g) holds features 16 dt + 4 g + {0..3}; after the
+        // swap of the (dt = 2 pr, 2 pr + 1) pair an even-g lane holds 16 (2 pr) + 4 g + {0..7}, an odd-g lane
+        // 16 (2 pr + 1) + 4 (g - 1) + {0..7}: 16-byte stores (the store tail is issue-bound, guide T21)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = q0 + t * 16;
+            const float inv = 1.0f / l[t];
+            u32x4_t ov[2];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const f32x4_t oa = o[t][2 * pr] * inv, ob = o[t][2 * pr + 1] * inv;
+                const auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(oa[0], oa[1]), pack_bf16x2(ob[0], ob[1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(oa[2], oa[3]), pack_bf16x2(ob[2], ob[3]), false, false);
+                ov[pr] = u32x4_t{lo[0], hi[0], lo[1], hi[1]};
+            }
+            if (q < N) {
+                bf16_t* dst = p.o + ((long long)b * N + q) * (H * DH) + h * DH + d_lane;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) *reinterpret_cast<u32x4_t*>(dst + 32 * pr) = ov[pr];
+                if (g == 0) p.lse[((long long)b * H + h) * N + q] = (m[t] + __builtin_amdgcn_logf(l[t])) * LN2;
+            }
         }
     }
 }
@@ -288,8 +480,213 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_dkv_kernel(const Attn
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, fused: one workgroup of 16 waves owns a (batch, head); Q, K, V and dO of the head are loaded into LDS
+// ONCE (4 x N x 128 B), phase 1 gives every wave one 16-query tile (dQ, delta -> LDS), phase 2 one 16-key tile
+// (dK, dV).  All MFMA operands come from the LDS images (row reads for the lane-owner side, transposed reads for the
+// contraction side); only O is read from HBM (for delta).  Compared with the two-kernel form this reads q/k/v/dO once
+// instead of twice, keeps delta on chip and halves the number of per-head load/compute phases.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATTB_THREADS = 1024;
+
+template <int NP>
+__global__ __launch_bounds__(ATTB_THREADS) void attn_bwd_fused_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* qimg = smem;
+    char* kimg = smem + NP * 128;
+    char* vimg = smem + 2 * NP * 128;
+    char* doimg = smem + 3 * NP * 128;
+    float* lse2s = reinterpret_cast<float*>(smem + 4 * NP * 128);
+    float* dels = lse2s + NP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const int N = p.N;
+    const long long ldq = 3ll * p.H * DH, ldo = (long long)p.H * DH;
+    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
+    const bf16_t* obase = p.out + (long long)b * N * ldo + h * DH;
+    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
+    load_image<NP, false, ATTB_THREADS>(qimg, qbase, ldq, N, tid);
+    load_image<NP, false, ATTB_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
+    load_image<NP, false, ATTB_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
+    load_image<NP, false, ATTB_THREADS>(doimg, dobase, ldo, N, tid);
+    for (int i = tid; i < NP; i += ATTB_THREADS)
+        lse2s[i] = i < N ? p.lse[((long long)b * p.H + h) * N + i] * LOG2E : INFINITY;      // exp2(s - inf) = 0 for padded queries
+
+    const int g = lane >> 4, lc = lane & 15;
+    const float sc = p.scale * LOG2E;
+    const int ntile = (N + 15) >> 4;
+    const bool active = wave < ntile;
+
+    // O rows of this wave's query tile for delta (the only HBM operand of the kernel besides the images)
+    float dl = 0.f;
+    {
+        const int q = wave * 16 + lc;
+        const int qr = q < N ? q : N - 1;
+        bf16x8_t of[2], dof[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            of[ks] = load_frag_global(obase + (long long)qr * ldo + ks * 32 + g * 8);
+            dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                dl += bf16_to_f32((unsigned short)dof[ks][e]) * bf16_to_f32((unsigned short)of[ks][e]);
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        if (g == 0 && q < NP) dels[q] = q < N ? dl : 0.f;
+    }
+    __syncthreads();
+
+    // ---- phase 1: query-owner -> dQ
+    if (active) {
+        const int q = wave * 16 + lc;
+        const float lse2 = lse2s[q];
+        bf16x8_t qf[2], dof[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = row_frag_img(qimg, wave * 16, ks, lane);
+            dof[ks] = row_frag_img(doimg, wave * 16, ks, lane);
+        }
+        f32x4_t dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kk = 0; kk < NP / 32; ++kk) {
+            f32x4_t ds[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int kb = kk * 32 + hf * 16;
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    st = mfma16(row_frag_img(kimg, kb, ks, lane), qf[ks], st);
+                    dp = mfma16(row_frag_img(vimg, kb, ks, lane), dof[ks], dp);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kb + 4 * g + e;
+                    const float pv = key < N ? __builtin_amdgcn_exp2f(st[e] * sc - lse2) : 0.f;
+                    ds[hf][e] = pv * (dp[e] - dl) * p.scale;
+                }
+            }
+            const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag_img(kimg, kk * 32, dt, lane), dsf, dq[dt]);
+        }
+        if (q < N) {
+            bf16_t* dst = p.dqkv + ((long long)b * N + q) * ldq + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, dq[dt]);
+        }
+    }
+
+    // ---- phase 2: key-owner -> dK, dV   (delta of every query is in LDS since the barrier above)
+    if (active) {
+        const int key = wave * 16 + lc;
+        bf16x8_t kf[2], vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = row_frag_img(kimg, wave * 16, ks, lane);
+            vf[ks] = row_frag_img(vimg, wave * 16, ks, lane);
+        }
+        f32x4_t dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dv[dt] = dk[dt];
+        }
+#pragma unroll 1
+        for (int qq = 0; qq < NP / 32; ++qq) {
+            f32x4_t pt[2], ds[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int qb = qq * 32 + hf * 16;
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    st = mfma16(row_frag_img(qimg, qb, ks, lane), kf[ks], st);
+                    dp = mfma16(row_frag_img(doimg, qb, ks, lane), vf[ks], dp);
+                }
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qb + 4 * g);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qb + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(st[e] * sc - l4[e]);
+                    pt[hf][e] = pv;
+                    ds[hf][e] = pv * (dp[e] - d4[e]) * p.scale;
+                }
+            }
+            const bf16x8_t pf = pack_frag(pt[0], pt[1]);
+            const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = mfma16(tr_frag_img(doimg, qq * 32, dt, lane), pf, dv[dt]);
+                dk[dt] = mfma16(tr_frag_img(qimg, qq * 32, dt, lane), dsf, dk[dt]);
+            }
+        }
+        if (key < N) {
+            bf16_t* dst = p.dqkv + ((long long)b * N + key) * ldq + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                store_bf16x4(dst + p.H * DH + dt * 16, dk[dt]);
+                store_bf16x4(dst + 2 * p.H * DH + dt * 16, dv[dt]);
+            }
+        }
+    }
+}
+
+constexpr size_t ATTN_STAMP_BYTES = 256 * 2 * 16 * 8 * 8;
+unsigned long long* attn_stamp_buffer() {
+    static unsigned long long* buf = [] {
+        void* q = nullptr;
+        if (hipMalloc(&q, ATTN_STAMP_BYTES) != hipSuccess) q = nullptr;
+        if (q) (void)hipMemset(q, 0, ATTN_STAMP_BYTES);
+        return static_cast<unsigned long long*>(q);
+    }();
+    return buf;
+}
+
+int attn_cus() {
+    static int n = [] {
+        int dev = 0, v = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+
+template <int NT>
+int launch_fwd_fat_nt(const AttnParams& p, hipStream_t s) {
+    constexpr int lds = 2 * NT * 16 * 128;
+    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_fat_kernel<NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL((attn_fwd_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATF_THREADS), lds, s, p);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
+// key tiles: the instantiated counts cover every N <= 256 with at most one tile of padding, and 13 exactly (N = 196 / 197)
+int launch_fwd_fat(const AttnParams& p, hipStream_t s) {
+    const int nt = (p.N + 15) / 16;
+    if (nt <= 2) return launch_fwd_fat_nt<2>(p, s);
+    if (nt <= 4) return launch_fwd_fat_nt<4>(p, s);
+    if (nt <= 6) return launch_fwd_fat_nt<6>(p, s);
+    if (nt <= 8) return launch_fwd_fat_nt<8>(p, s);
+    if (nt <= 10) return launch_fwd_fat_nt<10>(p, s);
+    if (nt <= 12) return launch_fwd_fat_nt<12>(p, s);
+    if (nt == 13) return launch_fwd_fat_nt<13>(p, s);
+    if (nt == 14) return launch_fwd_fat_nt<14>(p, s);
+    return launch_fwd_fat_nt<16>(p, s);
+}
+
 template <int NP>
 int launch_fwd(const AttnParams& p, hipStream_t s) {
+    static const int v1 = [] { const char* e = getenv("NRV_ATTN_FWD_V1"); return e ? atoi(e) : 0; }();
+    if (!v1) return launch_fwd_fat(p, s);
     constexpr int lds = 2 * NP * 128;
     static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NP>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -301,6 +698,18 @@ int launch_fwd(const AttnParams& p, hipStream_t s) {
 
 template <int NP>
 int launch_bwd(const AttnParams& p, hipStream_t s) {
+    // measured on MI355X (ViT-B/16, B = 256): fused 0.298 ms vs two kernels 0.277 ms -- one 16-wave workgroup per CU
+    // cannot overlap one head's loads with another head's MFMAs; kept opt-in (NRV_ATTN_BWD_FUSED=1)
+    static const int fused = [] { const char* e = getenv("NRV_ATTN_BWD_FUSED"); return e ? atoi(e) : 0; }();
+    if (fused) {
+        constexpr int lds = 4 * NP * 128 + 2 * NP * 4;
+        static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NP>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != 0) return attr;
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<NP>), dim3(p.B * p.H), dim3(ATTB_THREADS), lds, s, p);
+        NRV_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int lds_dq = 2 * NP * 128;
     constexpr int lds_dkv = 2 * NP * 128 + 2 * NP * 4;
     static int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NP>),
@@ -347,6 +756,9 @@ extern "C" int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
     p.o = static_cast<bf16_t*>(out_bf16);
     p.lse = lse;
     p.B = B; p.N = N; p.H = H; p.scale = scale;
+    static const int dbg = [] { const char* e = getenv("NRV_ATTN_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
+    p.stamps = (dbg & 4) ? attn_stamp_buffer() : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     NRV_DISPATCH_NP(N, launch_fwd<NPV>(p, s));
 }
@@ -368,4 +780,10 @@ extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const vo
     p.B = B; p.N = N; p.H = H; p.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     NRV_DISPATCH_NP(N, launch_bwd<NPV>(p, s));
+}
+
+extern "C" int nrv_debug_read_attn_stamps(unsigned long long* host_out, size_t count) {
+    unsigned long long* b = attn_stamp_buffer();
+    if (!b || !host_out || count * 8 > ATTN_STAMP_BYTES) return NRV_ERR_NULL;
+    return (int)hipMemcpy(host_out, b, count * 8, hipMemcpyDeviceToHost);
 }
