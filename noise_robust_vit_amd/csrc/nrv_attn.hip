@@ -481,6 +481,302 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_dkv_kernel(const Attn
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, fat waves (same recipe as attn_fwd_fat_kernel: 4 waves of <= 256 VGPRs per (batch, head), two workgroups per
+// CU, images by LDS-DMA, a wave owns TWO 16-row tiles so that every fragment read from LDS feeds both).
+//   dq kernel : images K, V; wave owns 32 queries, sweeps the keys 32 at a time  -> dQ, delta = rowsum(dO * O)
+//   dkv kernel: images Q, dO (+ lse, delta); wave owns 32 keys, sweeps the queries -> dK, dV
+// P is recomputed from the saved log-sum-exp; dS is scaled once at the end (dQ, dK are linear in it).
+// ---------------------------------------------------------------------------------------------
+// a 16 x 64 fp32 tile held as acc[dt][e] (lane (r = lane & 15, g = lane >> 4): row r, features 16 dt + 4 g + e) -> bf16,
+// regrouped with v_permlane16_swap so that a lane owns 8 consecutive features: two 16-byte stores per row
+__device__ __forceinline__ void store_tile_bf16(bf16_t* row_ptr /* row of this lane, feature 0 */, const f32x4_t (&acc)[4],
+                                                float mul, int g, bool ok) {
+    const int d_lane = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const f32x4_t a = acc[2 * pr] * mul, b = acc[2 * pr + 1] * mul;
+        const auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[2], a[3]), pack_bf16x2(b[2], b[3]), false, false);
+        if (ok) *reinterpret_cast<u32x4_t*>(row_ptr + 32 * pr + d_lane) = u32x4_t{lo[0], hi[0], lo[1], hi[1]};
+    }
+}
+
+// DMA of two [N x 64] head slices into two GEMM-swizzled row images of NT * 16 rows (rows >= N: zero)
+template <int NT>
+__device__ __forceinline__ void dma_two_images(char* smem, const bf16_t* src0, long long ld0, const bf16_t* src1, long long ld1,
+                                               int N, int wave, int lane) {
+    constexpr int NP = NT * 16;
+    const __amdgpu_buffer_rsrc_t r0 = make_rsrc(src0, 0x7fffffffull), r1 = make_rsrc(src1, 0x7fffffffull);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // scalar: the descriptor select below must stay in SGPRs
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {                  // 2 * NP / 8 = 4 NT instructions, NT per wave
+        const int j = wave_u * NT + i;
+        const bool second = j >= NP / 8;
+        const int r = 8 * (second ? j - NP / 8 : j) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const unsigned vo = (r < N) ? (unsigned)(r * (second ? ld1 : ld0) * 2 + c * 16) : NRV_OOB;
+        dma16(second ? r1 : r0, smem + j * 1024, vo);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = NT * 16;
+    constexpr int NS = (NT + 1) / 2;
+    constexpr int MT = (NT == 13 || NT == 14) ? 1 : 2;
+    const char* kimg = smem;
+    const char* vimg = smem + NP * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, H = p.H;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const long long ldq = 3ll * H * DH, ldo = (long long)H * DH;
+    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
+    const bf16_t* obase = p.out + (long long)b * N * ldo + h * DH;
+    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
+    const int g = lane >> 4, qc = lane & 15;
+    const float sc = p.scale * LOG2E;
+    const int npairs = (N + 31) >> 5;
+
+    bf16x8_t qf[2][2], dof[2][2];
+    float dl[2], lse2[2];
+    auto load_rows = [&](int pair) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = pair * 32 + t * 16 + qc;
+            const int qr = q < N ? q : N - 1;
+            float d = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qf[t][ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
+                dof[t][ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
+                const bf16x8_t of = load_frag_global(obase + (long long)qr * ldo + ks * 32 + g * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += bf16_to_f32((unsigned short)dof[t][ks][e]) * bf16_to_f32((unsigned short)of[e]);
+            }
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            dl[t] = d;
+            const long long sidx = ((long long)b * H + h) * N + qr;
+            lse2[t] = p.lse[sidx] * LOG2E;
+            if (g == 0 && q < N) p.delta[sidx] = d;
+        }
+    };
+    if (wave < npairs) load_rows(wave);
+    dma_two_images<NT>(smem, qbase + H * DH, ldq, qbase + 2 * H * DH, ldq, N, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __syncthreads();
+
+    const bf16x4_t zero4 = {0, 0, 0, 0};
+    for (int pair = wave; pair < npairs; pair += ATF_WAVES) {
+        f32x4_t dq[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        auto step = [&](const int kk, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;      // the last step: padding rows, and no upper half when NT is odd
+            f32x4_t ds[2][2];                                   // [tile][half]
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int kt = 2 * kk + hf;
+                if (!LAST || hf == 0 || (NT % 2 == 0)) {
+                    bf16x8_t kr[2], vr[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        kr[ks] = row_frag_img(kimg, kt * 16, ks, lane);
+                        vr[ks] = row_frag_img(vimg, kt * 16, ks, lane);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            st = mfma16(kr[ks], qf[t][ks], st);
+                            dp = mfma16(vr[ks], dof[t][ks], dp);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -lse2[t]));
+                            if (LAST) pv = (kt * 16 + 4 * g + e < N) ? pv : 0.f;
+                            ds[t][hf][e] = pv * (dp[e] - dl[t]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) ds[t][hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            bf16x8_t dsf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dsf[t] = pack_frag(ds[t][0], ds[t][1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                // K^T fragment: keys kk*32 .. +31 (the upper 16 do not exist in the last step when NT is odd), features 16 dt ..
+                const int q4 = (lane & 15) >> 2, pp = lane & 3;
+                const int r0 = kk * 32 + 4 * g + q4;
+                const int c = 2 * dt + (pp >> 1);
+                const bf16x4_t lo = lds_read_tr16_b64(kimg + img_off(r0, c) + (pp & 1) * 8);
+                const bf16x4_t hi = (!LAST || NT % 2 == 0) ? lds_read_tr16_b64(kimg + img_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
+                const bf16x8_t ktr = cat4(lo, hi);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dq[t][dt] = mfma16(ktr, dsf[t], dq[t][dt]);
+            }
+        };
+        // padding rows (key >= N) live in the last MT key tiles = the last step (MT == 2 only when NT is even)
+#pragma unroll 1
+        for (int kk = 0; kk < NS - 1; ++kk) step(kk, std::false_type{});
+        step(NS - 1, std::true_type{});
+        // next pair's rows while this pair's results are packed and stored
+        const int q0 = pair * 32 + qc;
+        f32x4_t keep[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) keep[t][dt] = dq[t][dt];
+        if (pair + ATF_WAVES < npairs) load_rows(pair + ATF_WAVES);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = q0 + t * 16;
+            store_tile_bf16(p.dqkv + ((long long)b * N + (q < N ? q : 0)) * ldq + h * DH, keep[t], p.scale, g, q < N);
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = NT * 16;
+    constexpr int NS = (NT + 1) / 2;
+    constexpr int NPS = NS * 32;                       // lse / delta arrays cover whole 32-query steps
+    const char* qimg = smem;
+    const char* doimg = smem + NP * 128;
+    float* lse2s = reinterpret_cast<float*>(smem + 2 * NP * 128);
+    float* dels = lse2s + NPS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, H = p.H;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const long long ldq = 3ll * H * DH, ldo = (long long)H * DH;
+    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
+    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
+    const int g = lane >> 4, kc = lane & 15;
+    const float sc = p.scale * LOG2E;
+    const int npairs = (N + 31) >> 5;
+
+    bf16x8_t kf[2][2], vf[2][2];
+    auto load_rows = [&](int pair) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = pair * 32 + t * 16 + kc;
+            const int kr = key < N ? key : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[t][ks] = load_frag_global(qbase + H * DH + (long long)kr * ldq + ks * 32 + g * 8);
+                vf[t][ks] = load_frag_global(qbase + 2 * H * DH + (long long)kr * ldq + ks * 32 + g * 8);
+            }
+        }
+    };
+    if (wave < npairs) load_rows(wave);
+    for (int i = tid; i < NPS; i += ATF_THREADS) {
+        const long long sidx = ((long long)b * H + h) * N + i;
+        lse2s[i] = i < N ? p.lse[sidx] * LOG2E : INFINITY;     // exp2(s - inf) = 0 for padded queries
+        dels[i] = i < N ? p.delta[sidx] : 0.f;
+    }
+    dma_two_images<NT>(smem, qbase, ldq, dobase, ldo, N, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __syncthreads();
+
+    const bf16x4_t zero4 = {0, 0, 0, 0};
+    auto tr_frag = [&](const char* img, int qq, int dt, auto last_c) {     // rows qq*32 .. +31 transposed, features 16 dt ..
+        const int q4 = (lane & 15) >> 2, pp = lane & 3;
+        const int r0 = qq * 32 + 4 * g + q4;
+        const int c = 2 * dt + (pp >> 1);
+        const bf16x4_t lo = lds_read_tr16_b64(img + img_off(r0, c) + (pp & 1) * 8);
+        const bf16x4_t hi = (!decltype(last_c)::value || NT % 2 == 0) ? lds_read_tr16_b64(img + img_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
+        return cat4(lo, hi);
+    };
+    for (int pair = wave; pair < npairs; pair += ATF_WAVES) {
+        f32x4_t dk[2][4], dv[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dk[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                dv[t][dt] = dk[t][dt];
+            }
+        auto step = [&](const int qq, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;      // the last step has no upper half when NT is odd
+            f32x4_t pt[2][2], ds[2][2];                         // [key tile][query half]
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int qt = 2 * qq + hf;
+                if (!LAST || hf == 0 || (NT % 2 == 0)) {
+                    bf16x8_t qr[2], dor[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        qr[ks] = row_frag_img(qimg, qt * 16, ks, lane);
+                        dor[ks] = row_frag_img(doimg, qt * 16, ks, lane);
+                    }
+                    const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qt * 16 + 4 * g);
+                    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qt * 16 + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            st = mfma16(qr[ks], kf[t][ks], st);
+                            dp = mfma16(dor[ks], vf[t][ks], dp);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -l4[e]));
+                            pt[t][hf][e] = pv;
+                            ds[t][hf][e] = pv * (dp[e] - d4[e]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        pt[t][hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        ds[t][hf] = pt[t][hf];
+                    }
+                }
+            }
+            bf16x8_t pf[2], dsf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pf[t] = pack_frag(pt[t][0], pt[t][1]);
+                dsf[t] = pack_frag(ds[t][0], ds[t][1]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t dotr = tr_frag(doimg, qq, dt, last_c);
+                const bf16x8_t qtr = tr_frag(qimg, qq, dt, last_c);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    dv[t][dt] = mfma16(dotr, pf[t], dv[t][dt]);
+                    dk[t][dt] = mfma16(qtr, dsf[t], dk[t][dt]);
+                }
+            }
+        };
+#pragma unroll 1
+        for (int qq = 0; qq < NS - 1; ++qq) step(qq, std::false_type{});
+        step(NS - 1, std::true_type{});
+        const int k0 = pair * 32 + kc;
+        if (pair + ATF_WAVES < npairs) load_rows(pair + ATF_WAVES);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = k0 + t * 16;
+            bf16_t* row = p.dqkv + ((long long)b * N + (key < N ? key : 0)) * ldq + h * DH;
+            store_tile_bf16(row + H * DH, dk[t], p.scale, g, key < N);
+            store_tile_bf16(row + 2 * H * DH, dv[t], 1.0f, g, key < N);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, fused: one workgroup of 16 waves owns a (batch, head); Q, K, V and dO of the head are loaded into LDS
 // ONCE (4 x N x 128 B), phase 1 gives every wave one 16-query tile (dQ, delta -> LDS), phase 2 one 16-key tile
 // (dK, dV).  All MFMA operands come from the LDS images (row reads for the lane-owner side, transposed reads for the
@@ -696,8 +992,40 @@ int launch_fwd(const AttnParams& p, hipStream_t s) {
     return 0;
 }
 
+template <int NT>
+int launch_bwd_fat_nt(const AttnParams& p, hipStream_t s) {
+    constexpr int lds_dq = 2 * NT * 16 * 128;
+    constexpr int lds_dkv = 2 * NT * 16 * 128 + 2 * ((NT + 1) / 2) * 32 * 4;
+    static int a1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_fat_kernel<NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    static int a2 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_fat_kernel<NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+    if (a1 != 0) return a1;
+    if (a2 != 0) return a2;
+    hipLaunchKernelGGL((attn_bwd_dq_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATF_THREADS), lds_dq, s, p);
+    NRV_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bwd_dkv_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATF_THREADS), lds_dkv, s, p);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_bwd_fat(const AttnParams& p, hipStream_t s) {
+    const int nt = (p.N + 15) / 16;
+    if (nt <= 2) return launch_bwd_fat_nt<2>(p, s);
+    if (nt <= 4) return launch_bwd_fat_nt<4>(p, s);
+    if (nt <= 6) return launch_bwd_fat_nt<6>(p, s);
+    if (nt <= 8) return launch_bwd_fat_nt<8>(p, s);
+    if (nt <= 10) return launch_bwd_fat_nt<10>(p, s);
+    if (nt <= 12) return launch_bwd_fat_nt<12>(p, s);
+    if (nt == 13) return launch_bwd_fat_nt<13>(p, s);
+    if (nt == 14) return launch_bwd_fat_nt<14>(p, s);
+    return launch_bwd_fat_nt<16>(p, s);
+}
+
 template <int NP>
 int launch_bwd(const AttnParams& p, hipStream_t s) {
+    static const int v1 = [] { const char* e = getenv("NRV_ATTN_BWD_V1"); return e ? atoi(e) : 0; }();
+    if (!v1) return launch_bwd_fat(p, s);
     // measured on MI355X (ViT-B/16, B = 256): fused 0.298 ms vs two kernels 0.277 ms -- one 16-wave workgroup per CU
     // cannot overlap one head's loads with another head's MFMAs; kept opt-in (NRV_ATTN_BWD_FUSED=1)
     static const int fused = [] { const char* e = getenv("NRV_ATTN_BWD_FUSED"); return e ? atoi(e) : 0; }();
