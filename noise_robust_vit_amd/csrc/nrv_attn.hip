@@ -1,21 +1,24 @@
 // Fused multi-head self-attention, forward and backward, for gfx950 (MI355X).
 //
-// ViT heads are tiny (N <= 256 tokens, dh = 64), so one workgroup (4 waves) owns one (batch, head):
-// the whole K and V of the head live in LDS (2 x N x 128 B), a wave owns 16 query rows at a time and
-// holds the full score row block in registers -- single-pass softmax, no online rescale, and the
-// [N,N] score matrix never leaves the CU (the reference materialises it three times:
-// simple_vit.py:70-74).  q/k/v are read in place from the QKV projection's [B, N, 3*H*dh] output
-// (128-byte head segments), and the output is written in 'b n (h d)' order, so the einops
+// ViT heads are tiny (N <= 256 tokens, dh = 64): one workgroup owns one (batch, head), the whole K and V (or Q and dO)
+// of the head live in LDS as swizzled row images, and the [N,N] score matrix never leaves the CU (the reference
+// materialises it three times: simple_vit.py:70-74).  q/k/v are read in place from the QKV projection's
+// [B, N, 3*H*dh] output (128-byte head segments) and the output is written in 'b n (h d)' order, so the einops
 // rearrange copies (simple_vit.py:68,75) disappear.
 //
-// MFMA orientation (16x16x32 bf16): scores are computed TRANSPOSED, S^T = K Q^T, so a lane owns one
-// query column and its keys sit in registers: row max / row sum are register reductions plus two
-// shuffles, and the bf16 P^T accumulator IS the B operand of O^T = V^T P^T (no lane movement).
-// V^T (and K^T, Q^T, dO^T in the backward) fragments come from ds_read_b64_tr_b16.
+// MFMA orientation (16x16x32 bf16): scores are computed TRANSPOSED, S^T = K Q^T, so a lane owns one query column and
+// its keys sit in registers: row max / row sum are register reductions plus two shuffles, and the bf16 P^T accumulator
+// IS the B operand of O^T = V^T P^T (no lane movement).  V^T (and K^T, Q^T, dO^T in the backward) fragments come from
+// ds_read_b64_tr_b16.
+//
+// "Fat waves": 4 waves of <= 256 VGPRs per workgroup (one per SIMD), 2-3 workgroups per CU; a wave owns TWO 16-row
+// tiles so that every fragment read from LDS feeds both; images arrive by 16-byte LDS-DMA.  What the earlier
+// thin-wave form (8 waves x 128 VGPRs, one tile per wave, register-staged images) lost, measured with s_memtime stamps:
+// every ds_read was followed by a full lgkmcnt(0) wait (no registers to run reads ahead), 6.8 us of arithmetic per head.
 //
 // Backward = two kernels with the same structure and no atomics:
-//   dq kernel : wave owns 16 queries, sweeps keys  -> dQ, and delta = rowsum(dO * O)
-//   dkv kernel: wave owns 16 keys,   sweeps queries -> dK, dV
+//   dq kernel : wave owns 32 queries, sweeps keys    -> dQ, and delta = rowsum(dO * O)
+//   dkv kernel: wave owns 32 keys,    sweeps queries -> dK, dV
 // P is recomputed from q, k and the saved log-sum-exp.
 #include <stdlib.h>
 
@@ -26,9 +29,6 @@
 namespace {
 
 using namespace nrv_attn;
-constexpr int ATT_THREADS = 512;      // 8 waves per (batch, head); 2 workgroups per CU -> 4 waves per SIMD
-constexpr int ATT_WAVES = ATT_THREADS / 64;
-
 struct AttnParams {
     const bf16_t* qkv;     // [B, N, 3*H*64]
     const bf16_t* out;     // [B, N, H*64]      (bwd)
@@ -39,101 +39,7 @@ struct AttnParams {
     float* delta;          // [B, H, N]
     int B, N, H;
     float scale;
-    unsigned long long* stamps;   // dev only (NRV_ATTN_DBG=3)
-    int dbg;               // dev only (NRV_ATTN_DBG bit mask): 1 = skip compute, 2 = skip the per-head loads after the first, 4 = stamps
 };
-
-// ---------------------------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kimg = smem;
-    char* vimg = smem + NP * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-    const int N = p.N;
-    const long long ldq = 3ll * p.H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    load_image<NP, false, ATT_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
-    load_image<NP, true, ATT_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
-
-    const int g = lane >> 4, qc = lane & 15;
-    const float sc = p.scale * LOG2E;
-    const int nqt = (N + 15) >> 4;
-    // the wave's first query fragments are fetched while the K/V images are still landing
-    bf16x8_t qf[2];
-    {
-        const int q0 = wave * 16 + qc;
-        const int qr0 = q0 < N ? q0 : N - 1;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = load_frag_global(qbase + (long long)qr0 * ldq + ks * 32 + g * 8);
-    }
-    __syncthreads();
-
-    // Two passes over the keys keep the register footprint small (<= 128 VGPRs => two workgroups = 16 waves per CU,
-    // which is what hides the per-head load latency): pass 1 finds the row maximum, pass 2 recomputes the score
-    // tiles, exponentiates and feeds P.V.  The extra K.Q^T MFMAs are free -- this kernel is latency-, not MFMA-bound.
-    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
-        const int q = qt * 16 + qc;
-        float m = -INFINITY;
-#pragma unroll 2
-        for (int kt = 0; kt < NP / 16; ++kt) {
-            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) st = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[ks], st);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = kt * 16 + 4 * g + e;
-                m = fmaxf(m, key < N ? st[e] * sc : -INFINITY);
-            }
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-
-        float l = 0.f;
-        f32x4_t o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int kk = 0; kk < NP / 32; ++kk) {
-            f32x4_t pt[2];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) st = mfma16(row_frag_img(kimg, kk * 32 + hf * 16, ks, lane), qf[ks], st);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = kk * 32 + hf * 16 + 4 * g + e;
-                    const float pv = key < N ? __builtin_amdgcn_exp2f(st[e] * sc - m) : 0.f;
-                    pt[hf][e] = pv;
-                    l += pv;
-                }
-            }
-            const bf16x8_t pf = pack_frag(pt[0], pt[1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag_vimg(vimg, kk * 32, dt, lane), pf, o[dt]);
-        }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        // next tile's query fragments (if any) before the stores of this one
-        const int qn = (qt + ATT_WAVES) * 16 + qc;
-        if (qt + ATT_WAVES < nqt) {
-            const int qrn = qn < N ? qn : N - 1;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) qf[ks] = load_frag_global(qbase + (long long)qrn * ldq + ks * 32 + g * 8);
-        }
-        if (q < N) {
-            const float inv = 1.0f / l;
-            bf16_t* dst = p.o + ((long long)b * N + q) * (p.H * DH) + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, o[dt] * inv);
-            if (g == 0) p.lse[((long long)b * p.H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // forward, 4 fat waves: one workgroup of 4 waves (one per SIMD, <= 256 VGPRs) per (batch, head), TWO workgroups per CU.
@@ -322,165 +228,6 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_ke
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, query-owner pass: dQ and delta
-// ---------------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_dq_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kimg = smem;
-    char* vimg = smem + NP * 128;      // GEMM-swizzled row image here (row reads only)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-    const int N = p.N;
-    const long long ldq = 3ll * p.H * DH, ldo = (long long)p.H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    const bf16_t* obase = p.out + (long long)b * N * ldo + h * DH;
-    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
-    load_image<NP, false, ATT_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
-    load_image<NP, false, ATT_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
-    __syncthreads();
-
-    const int g = lane >> 4, qc = lane & 15;
-    const float sc = p.scale * LOG2E;
-    const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
-        const int q = qt * 16 + qc;
-        const int qr = q < N ? q : N - 1;
-        bf16x8_t qf[2], dof[2];
-        float dl = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
-            dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
-            const bf16x8_t of = load_frag_global(obase + (long long)qr * ldo + ks * 32 + g * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                dl += bf16_to_f32((unsigned short)dof[ks][e]) * bf16_to_f32((unsigned short)of[e]);
-        }
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
-        const long long sidx = ((long long)b * p.H + h) * N + qr;
-        const float lse2 = p.lse[sidx] * LOG2E;
-        if (g == 0 && q < N) p.delta[sidx] = dl;
-
-        f32x4_t dq[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int kk = 0; kk < NP / 32; ++kk) {
-            f32x4_t ds[2];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int kb = kk * 32 + hf * 16;
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    st = mfma16(row_frag_img(kimg, kb, ks, lane), qf[ks], st);
-                    dp = mfma16(row_frag_img(vimg, kb, ks, lane), dof[ks], dp);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = kb + 4 * g + e;
-                    const float pv = key < N ? __builtin_amdgcn_exp2f(st[e] * sc - lse2) : 0.f;
-                    ds[hf][e] = pv * (dp[e] - dl) * p.scale;
-                }
-            }
-            const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag_img(kimg, kk * 32, dt, lane), dsf, dq[dt]);
-        }
-        if (q < N) {
-            bf16_t* dst = p.dqkv + ((long long)b * N + q) * ldq + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, dq[dt]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// backward, key-owner pass: dK and dV
-// ---------------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_dkv_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* qimg = smem;
-    char* doimg = smem + NP * 128;
-    float* lse2s = reinterpret_cast<float*>(smem + 2 * NP * 128);
-    float* dels = lse2s + NP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-    const int N = p.N;
-    const long long ldq = 3ll * p.H * DH, ldo = (long long)p.H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
-    load_image<NP, false, ATT_THREADS>(qimg, qbase, ldq, N, tid);
-    load_image<NP, false, ATT_THREADS>(doimg, dobase, ldo, N, tid);
-    for (int i = tid; i < NP; i += ATT_THREADS) {
-        const long long sidx = ((long long)b * p.H + h) * N + i;
-        lse2s[i] = i < N ? p.lse[sidx] * LOG2E : INFINITY;     // exp2(s - inf) = 0 for padded queries
-        dels[i] = i < N ? p.delta[sidx] : 0.f;
-    }
-    __syncthreads();
-
-    const int g = lane >> 4, kc = lane & 15;
-    const float sc = p.scale * LOG2E;
-    const int nkt = (N + 15) >> 4;
-    for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
-        const int key = kt * 16 + kc;
-        const int kr = key < N ? key : N - 1;
-        bf16x8_t kf[2], vf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[ks] = load_frag_global(qbase + p.H * DH + (long long)kr * ldq + ks * 32 + g * 8);
-            vf[ks] = load_frag_global(qbase + 2 * p.H * DH + (long long)kr * ldq + ks * 32 + g * 8);
-        }
-        f32x4_t dk[4], dv[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            dv[dt] = dk[dt];
-        }
-#pragma unroll 1
-        for (int qq = 0; qq < NP / 32; ++qq) {
-            f32x4_t pt[2], ds[2];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int qb = qq * 32 + hf * 16;
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    st = mfma16(row_frag_img(qimg, qb, ks, lane), kf[ks], st);
-                    dp = mfma16(row_frag_img(doimg, qb, ks, lane), vf[ks], dp);
-                }
-                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qb + 4 * g);
-                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qb + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(st[e] * sc - l4[e]);
-                    pt[hf][e] = pv;
-                    ds[hf][e] = pv * (dp[e] - d4[e]) * p.scale;
-                }
-            }
-            const bf16x8_t pf = pack_frag(pt[0], pt[1]);
-            const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = mfma16(tr_frag_img(doimg, qq * 32, dt, lane), pf, dv[dt]);
-                dk[dt] = mfma16(tr_frag_img(qimg, qq * 32, dt, lane), dsf, dk[dt]);
-            }
-        }
-        if (key < N) {
-            bf16_t* dst = p.dqkv + ((long long)b * N + key) * ldq + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                store_bf16x4(dst + p.H * DH + dt * 16, dk[dt]);
-                store_bf16x4(dst + 2 * p.H * DH + dt * 16, dv[dt]);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // backward, fat waves (same recipe as attn_fwd_fat_kernel: 4 waves of <= 256 VGPRs per (batch, head), two workgroups per
 // CU, images by LDS-DMA, a wave owns TWO 16-row tiles so that every fragment read from LDS feeds both).
 //   dq kernel : images K, V; wave owns 32 queries, sweeps the keys 32 at a time  -> dQ, delta = rowsum(dO * O)
@@ -515,7 +262,8 @@ __device__ __forceinline__ void dma_two_images(char* smem, const bf16_t* src0, l
         const int r = 8 * (second ? j - NP / 8 : j) + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const unsigned vo = (r < N) ? (unsigned)(r * (second ? ld1 : ld0) * 2 + c * 16) : NRV_OOB;
-        dma16(second ? r1 : r0, smem + j * 1024, vo);
+        if (second) dma16(r1, smem + j * 1024, vo);
+        else dma16(r0, smem + j * 1024, vo);
     }
 }
 
@@ -777,181 +525,256 @@ __global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, fused: one workgroup of 16 waves owns a (batch, head); Q, K, V and dO of the head are loaded into LDS
-// ONCE (4 x N x 128 B), phase 1 gives every wave one 16-query tile (dQ, delta -> LDS), phase 2 one 16-key tile
-// (dK, dV).  All MFMA operands come from the LDS images (row reads for the lane-owner side, transposed reads for the
-// contraction side); only O is read from HBM (for delta).  Compared with the two-kernel form this reads q/k/v/dO once
-// instead of twice, keeps delta on chip and halves the number of per-head load/compute phases.
+// backward, fused fat waves: ONE workgroup of 8 waves (2 per SIMD, <= 256 VGPRs) per (batch, head) holds the four
+// images Q, K, V, dO in LDS (4 x NT x 2 KiB), loaded once by LDS-DMA: 200 KB of HBM traffic per head instead of the
+// 300 KB of the two-kernel form (which reads q, k, v, dO twice).  After a short prologue (delta = rowsum(dO * O) for
+// 32 rows per wave -> LDS) the waves split by ROLE: waves 0-3 own query tiles (dQ), waves 4-7 own key tiles (dK, dV);
+// the two waves of a SIMD (w and w + 4) therefore run different phases of different work, and all row fragments of
+// the owned tiles come from the images (no second trip to HBM).
 // ---------------------------------------------------------------------------------------------
-constexpr int ATTB_THREADS = 1024;
+constexpr int ATB_THREADS = 512;
 
-template <int NP>
-__global__ __launch_bounds__(ATTB_THREADS) void attn_bwd_fused_kernel(const AttnParams p) {
+template <int NT>
+__global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* qimg = smem;
-    char* kimg = smem + NP * 128;
-    char* vimg = smem + 2 * NP * 128;
-    char* doimg = smem + 3 * NP * 128;
-    float* lse2s = reinterpret_cast<float*>(smem + 4 * NP * 128);
-    float* dels = lse2s + NP;
+    constexpr int NP = NT * 16;
+    constexpr int NS = (NT + 1) / 2;
+    constexpr int NPS = NS * 32;
+    constexpr int IMG = NP * 128;
+    const char* qimg = smem;
+    const char* kimg = smem + IMG;
+    const char* vimg = smem + 2 * IMG;
+    const char* doimg = smem + 3 * IMG;
+    float* lse2s = reinterpret_cast<float*>(smem + 4 * IMG);
+    float* dels = lse2s + NPS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-    const int N = p.N;
-    const long long ldq = 3ll * p.H * DH, ldo = (long long)p.H * DH;
+    const int N = p.N, H = p.H;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const long long ldq = 3ll * H * DH, ldo = (long long)H * DH;
     const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
     const bf16_t* obase = p.out + (long long)b * N * ldo + h * DH;
     const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
-    load_image<NP, false, ATTB_THREADS>(qimg, qbase, ldq, N, tid);
-    load_image<NP, false, ATTB_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
-    load_image<NP, false, ATTB_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
-    load_image<NP, false, ATTB_THREADS>(doimg, dobase, ldo, N, tid);
-    for (int i = tid; i < NP; i += ATTB_THREADS)
-        lse2s[i] = i < N ? p.lse[((long long)b * p.H + h) * N + i] * LOG2E : INFINITY;      // exp2(s - inf) = 0 for padded queries
-
-    const int g = lane >> 4, lc = lane & 15;
+    const int g = lane >> 4, rc = lane & 15;
     const float sc = p.scale * LOG2E;
-    const int ntile = (N + 15) >> 4;
-    const bool active = wave < ntile;
+    const int npairs = (N + 31) >> 5;
 
-    // O rows of this wave's query tile for delta (the only HBM operand of the kernel besides the images)
-    float dl = 0.f;
-    {
-        const int q = wave * 16 + lc;
+    // ---- prologue: O rows of this wave's 32 queries (registers), then the four images
+    bf16x8_t of[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int q = wave * 32 + t * 16 + rc;
         const int qr = q < N ? q : N - 1;
-        bf16x8_t of[2], dof[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            of[ks] = load_frag_global(obase + (long long)qr * ldo + ks * 32 + g * 8);
-            dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
+        for (int ks = 0; ks < 2; ++ks) of[t][ks] = load_frag_global(obase + (long long)qr * ldo + ks * 32 + g * 8);
+    }
+    for (int i = tid; i < NPS; i += ATB_THREADS)
+        lse2s[i] = i < N ? p.lse[((long long)b * H + h) * N + i] * LOG2E : INFINITY;      // exp2(s - inf) = 0 for padded queries
+    {
+        const __amdgpu_buffer_rsrc_t rq = make_rsrc(qbase, 0x7fffffffull), rd = make_rsrc(dobase, 0x7fffffffull);
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {                  // 4 images x NP / 8 = 8 NT instructions, NT per wave
+            const int j = wave_u * NT + i;
+            const int im = j / (NP / 8);                // 0 q, 1 k, 2 v, 3 dO
+            const int r = 8 * (j - im * (NP / 8)) + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const unsigned vo = (r < N) ? (unsigned)(r * (im == 3 ? ldo : ldq) * 2 + c * 16 + (im == 3 ? 0 : im) * H * DH * 2) : NRV_OOB;
+            if (im == 3) dma16(rd, smem + j * 1024, vo);      // (a select between descriptors may end up in VGPRs)
+            else dma16(rq, smem + j * 1024, vo);
         }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    // delta of 32 rows per wave (8 x 32 = 256 >= NPS rows)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+    for (int t = 0; t < 2; ++t) {
+        const int q = wave * 32 + t * 16 + rc;
+        if (wave * 32 + t * 16 < NP) {
+            float d = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                dl += bf16_to_f32((unsigned short)dof[ks][e]) * bf16_to_f32((unsigned short)of[ks][e]);
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
-        if (g == 0 && q < NP) dels[q] = q < N ? dl : 0.f;
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t dof = row_frag_img(doimg, wave * 32 + t * 16, ks, lane);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += bf16_to_f32((unsigned short)dof[e]) * bf16_to_f32((unsigned short)of[t][ks][e]);
+            }
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            if (g == 0) dels[q] = q < N ? d : 0.f;
+        } else if (wave * 32 + t * 16 < NPS) {
+            if (g == 0) dels[q] = 0.f;
+        }
     }
     __syncthreads();
 
-    // ---- phase 1: query-owner -> dQ
-    if (active) {
-        const int q = wave * 16 + lc;
-        const float lse2 = lse2s[q];
-        bf16x8_t qf[2], dof[2];
+    const bf16x4_t zero4 = {0, 0, 0, 0};
+    auto tr_frag = [&](const char* img, int s32, int dt, auto last_c) {     // rows s32*32 .. +31 transposed, features 16 dt ..
+        const int q4 = (lane & 15) >> 2, pp = lane & 3;
+        const int r0 = s32 * 32 + 4 * g + q4;
+        const int c = 2 * dt + (pp >> 1);
+        const bf16x4_t lo = lds_read_tr16_b64(img + img_off(r0, c) + (pp & 1) * 8);
+        const bf16x4_t hi = (!decltype(last_c)::value || NT % 2 == 0) ? lds_read_tr16_b64(img + img_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
+        return cat4(lo, hi);
+    };
+
+    if (wave < 4) {
+        // ================= role: query owner -> dQ
+        for (int pair = wave; pair < npairs; pair += 4) {
+            bf16x8_t qf[2][2], dof[2][2];
+            float dl[2], lse2[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = row_frag_img(qimg, wave * 16, ks, lane);
-            dof[ks] = row_frag_img(doimg, wave * 16, ks, lane);
-        }
-        f32x4_t dq[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int kk = 0; kk < NP / 32; ++kk) {
-            f32x4_t ds[2];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int kb = kk * 32 + hf * 16;
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    st = mfma16(row_frag_img(kimg, kb, ks, lane), qf[ks], st);
-                    dp = mfma16(row_frag_img(vimg, kb, ks, lane), dof[ks], dp);
+                    qf[t][ks] = row_frag_img(qimg, pair * 32 + t * 16, ks, lane);
+                    dof[t][ks] = row_frag_img(doimg, pair * 32 + t * 16, ks, lane);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = kb + 4 * g + e;
-                    const float pv = key < N ? __builtin_amdgcn_exp2f(st[e] * sc - lse2) : 0.f;
-                    ds[hf][e] = pv * (dp[e] - dl) * p.scale;
-                }
+                dl[t] = dels[pair * 32 + t * 16 + rc];
+                lse2[t] = lse2s[pair * 32 + t * 16 + rc];
             }
-            const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
+            f32x4_t dq[2][4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag_img(kimg, kk * 32, dt, lane), dsf, dq[dt]);
-        }
-        if (q < N) {
-            bf16_t* dst = p.dqkv + ((long long)b * N + q) * ldq + h * DH + 4 * g;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, dq[dt]);
-        }
-    }
-
-    // ---- phase 2: key-owner -> dK, dV   (delta of every query is in LDS since the barrier above)
-    if (active) {
-        const int key = wave * 16 + lc;
-        bf16x8_t kf[2], vf[2];
+                for (int dt = 0; dt < 4; ++dt) dq[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            auto step = [&](const int kk, auto last_c) {
+                constexpr bool LAST = decltype(last_c)::value;
+                f32x4_t ds[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[ks] = row_frag_img(kimg, wave * 16, ks, lane);
-            vf[ks] = row_frag_img(vimg, wave * 16, ks, lane);
-        }
-        f32x4_t dk[4], dv[4];
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int kt = 2 * kk + hf;
+                    if (!LAST || hf == 0 || (NT % 2 == 0)) {
+                        bf16x8_t kr[2], vr[2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            dv[dt] = dk[dt];
-        }
+                        for (int ks = 0; ks < 2; ++ks) {
+                            kr[ks] = row_frag_img(kimg, kt * 16, ks, lane);
+                            vr[ks] = row_frag_img(vimg, kt * 16, ks, lane);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks) {
+                                st = mfma16(kr[ks], qf[t][ks], st);
+                                dp = mfma16(vr[ks], dof[t][ks], dp);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -lse2[t]));
+                                if (LAST) pv = (kt * 16 + 4 * g + e < N) ? pv : 0.f;
+                                ds[t][hf][e] = pv * (dp[e] - dl[t]);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) ds[t][hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                bf16x8_t dsf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dsf[t] = pack_frag(ds[t][0], ds[t][1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8_t ktr = tr_frag(kimg, kk, dt, last_c);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) dq[t][dt] = mfma16(ktr, dsf[t], dq[t][dt]);
+                }
+            };
 #pragma unroll 1
-        for (int qq = 0; qq < NP / 32; ++qq) {
-            f32x4_t pt[2], ds[2];
+            for (int kk = 0; kk < NS - 1; ++kk) step(kk, std::false_type{});
+            step(NS - 1, std::true_type{});
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int qb = qq * 32 + hf * 16;
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 2; ++t) {
+                const int q = pair * 32 + t * 16 + rc;
+                store_tile_bf16(p.dqkv + ((long long)b * N + (q < N ? q : 0)) * ldq + h * DH, dq[t], p.scale, g, q < N);
+            }
+        }
+    } else {
+        // ================= role: key owner -> dK, dV
+        for (int pair = wave - 4; pair < npairs; pair += 4) {
+            bf16x8_t kf[2][2], vf[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    st = mfma16(row_frag_img(qimg, qb, ks, lane), kf[ks], st);
-                    dp = mfma16(row_frag_img(doimg, qb, ks, lane), vf[ks], dp);
+                    kf[t][ks] = row_frag_img(kimg, pair * 32 + t * 16, ks, lane);
+                    vf[t][ks] = row_frag_img(vimg, pair * 32 + t * 16, ks, lane);
                 }
-                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qb + 4 * g);
-                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qb + 4 * g);
+            f32x4_t dk[2][4], dv[2][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(st[e] * sc - l4[e]);
-                    pt[hf][e] = pv;
-                    ds[hf][e] = pv * (dp[e] - d4[e]) * p.scale;
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dk[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    dv[t][dt] = dk[t][dt];
                 }
-            }
-            const bf16x8_t pf = pack_frag(pt[0], pt[1]);
-            const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
+            auto step = [&](const int qq, auto last_c) {
+                constexpr bool LAST = decltype(last_c)::value;
+                f32x4_t pt[2][2], ds[2][2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = mfma16(tr_frag_img(doimg, qq * 32, dt, lane), pf, dv[dt]);
-                dk[dt] = mfma16(tr_frag_img(qimg, qq * 32, dt, lane), dsf, dk[dt]);
-            }
-        }
-        if (key < N) {
-            bf16_t* dst = p.dqkv + ((long long)b * N + key) * ldq + h * DH + 4 * g;
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int qt = 2 * qq + hf;
+                    if (!LAST || hf == 0 || (NT % 2 == 0)) {
+                        bf16x8_t qr[2], dor[2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                store_bf16x4(dst + p.H * DH + dt * 16, dk[dt]);
-                store_bf16x4(dst + 2 * p.H * DH + dt * 16, dv[dt]);
+                        for (int ks = 0; ks < 2; ++ks) {
+                            qr[ks] = row_frag_img(qimg, qt * 16, ks, lane);
+                            dor[ks] = row_frag_img(doimg, qt * 16, ks, lane);
+                        }
+                        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qt * 16 + 4 * g);
+                        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qt * 16 + 4 * g);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks) {
+                                st = mfma16(qr[ks], kf[t][ks], st);
+                                dp = mfma16(dor[ks], vf[t][ks], dp);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -l4[e]));
+                                pt[t][hf][e] = pv;
+                                ds[t][hf][e] = pv * (dp[e] - d4[e]);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            pt[t][hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                            ds[t][hf] = pt[t][hf];
+                        }
+                    }
+                }
+                bf16x8_t pf[2], dsf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    pf[t] = pack_frag(pt[t][0], pt[t][1]);
+                    dsf[t] = pack_frag(ds[t][0], ds[t][1]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8_t dotr = tr_frag(doimg, qq, dt, last_c);
+                    const bf16x8_t qtr = tr_frag(qimg, qq, dt, last_c);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        dv[t][dt] = mfma16(dotr, pf[t], dv[t][dt]);
+                        dk[t][dt] = mfma16(qtr, dsf[t], dk[t][dt]);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int qq = 0; qq < NS - 1; ++qq) step(qq, std::false_type{});
+            step(NS - 1, std::true_type{});
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int key = pair * 32 + t * 16 + rc;
+                bf16_t* row = p.dqkv + ((long long)b * N + (key < N ? key : 0)) * ldq + h * DH;
+                store_tile_bf16(row + H * DH, dk[t], p.scale, g, key < N);
+                store_tile_bf16(row + 2 * H * DH, dv[t], 1.0f, g, key < N);
             }
         }
     }
-}
-
-constexpr size_t ATTN_STAMP_BYTES = 256 * 2 * 16 * 8 * 8;
-unsigned long long* attn_stamp_buffer() {
-    static unsigned long long* buf = [] {
-        void* q = nullptr;
-        if (hipMalloc(&q, ATTN_STAMP_BYTES) != hipSuccess) q = nullptr;
-        if (q) (void)hipMemset(q, 0, ATTN_STAMP_BYTES);
-        return static_cast<unsigned long long*>(q);
-    }();
-    return buf;
-}
-
-int attn_cus() {
-    static int n = [] {
-        int dev = 0, v = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
-        return v > 0 ? v : 256;
-    }();
-    return n;
 }
 
 template <int NT>
@@ -979,19 +802,6 @@ int launch_fwd_fat(const AttnParams& p, hipStream_t s) {
     return launch_fwd_fat_nt<16>(p, s);
 }
 
-template <int NP>
-int launch_fwd(const AttnParams& p, hipStream_t s) {
-    static const int v1 = [] { const char* e = getenv("NRV_ATTN_FWD_V1"); return e ? atoi(e) : 0; }();
-    if (!v1) return launch_fwd_fat(p, s);
-    constexpr int lds = 2 * NP * 128;
-    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NP>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (attr != 0) return attr;
-    hipLaunchKernelGGL((attn_fwd_kernel<NP>), dim3(p.B * p.H), dim3(ATT_THREADS), lds, s, p);
-    NRV_CHECK_LAUNCH();
-    return 0;
-}
-
 template <int NT>
 int launch_bwd_fat_nt(const AttnParams& p, hipStream_t s) {
     constexpr int lds_dq = 2 * NT * 16 * 128;
@@ -1009,8 +819,33 @@ int launch_bwd_fat_nt(const AttnParams& p, hipStream_t s) {
     return 0;
 }
 
+template <int NT>
+int launch_bwd_fused_fat_nt(const AttnParams& p, hipStream_t s) {
+    constexpr int lds = 4 * NT * 16 * 128 + 2 * ((NT + 1) / 2) * 32 * 4;
+    static int a1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_fat_kernel<NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (a1 != 0) return a1;
+    hipLaunchKernelGGL((attn_bwd_fused_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATB_THREADS), lds, s, p);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_bwd_fat(const AttnParams& p, hipStream_t s) {
     const int nt = (p.N + 15) / 16;
+    // single-kernel form (attn_bwd_fused_fat_kernel): 2/3 of the HBM traffic but one workgroup per CU, so a head's loads
+    // are not overlapped with another head's arithmetic: measured equal (0.245 vs 0.244 ms); opt-in until it prefetches
+    static const int fused = [] { const char* e = getenv("NRV_ATTN_BWD_FUSED"); return e ? atoi(e) : 0; }();
+    if (fused) {
+        if (nt <= 2) return launch_bwd_fused_fat_nt<2>(p, s);
+        if (nt <= 4) return launch_bwd_fused_fat_nt<4>(p, s);
+        if (nt <= 6) return launch_bwd_fused_fat_nt<6>(p, s);
+        if (nt <= 8) return launch_bwd_fused_fat_nt<8>(p, s);
+        if (nt <= 10) return launch_bwd_fused_fat_nt<10>(p, s);
+        if (nt <= 12) return launch_bwd_fused_fat_nt<12>(p, s);
+        if (nt == 13) return launch_bwd_fused_fat_nt<13>(p, s);
+        if (nt == 14) return launch_bwd_fused_fat_nt<14>(p, s);
+        return launch_bwd_fused_fat_nt<16>(p, s);
+    }
     if (nt <= 2) return launch_bwd_fat_nt<2>(p, s);
     if (nt <= 4) return launch_bwd_fat_nt<4>(p, s);
     if (nt <= 6) return launch_bwd_fat_nt<6>(p, s);
@@ -1022,55 +857,12 @@ int launch_bwd_fat(const AttnParams& p, hipStream_t s) {
     return launch_bwd_fat_nt<16>(p, s);
 }
 
-template <int NP>
-int launch_bwd(const AttnParams& p, hipStream_t s) {
-    static const int v1 = [] { const char* e = getenv("NRV_ATTN_BWD_V1"); return e ? atoi(e) : 0; }();
-    if (!v1) return launch_bwd_fat(p, s);
-    // measured on MI355X (ViT-B/16, B = 256): fused 0.298 ms vs two kernels 0.277 ms -- one 16-wave workgroup per CU
-    // cannot overlap one head's loads with another head's MFMAs; kept opt-in (NRV_ATTN_BWD_FUSED=1)
-    static const int fused = [] { const char* e = getenv("NRV_ATTN_BWD_FUSED"); return e ? atoi(e) : 0; }();
-    if (fused) {
-        constexpr int lds = 4 * NP * 128 + 2 * NP * 4;
-        static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NP>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (attr != 0) return attr;
-        hipLaunchKernelGGL((attn_bwd_fused_kernel<NP>), dim3(p.B * p.H), dim3(ATTB_THREADS), lds, s, p);
-        NRV_CHECK_LAUNCH();
-        return 0;
-    }
-    constexpr int lds_dq = 2 * NP * 128;
-    constexpr int lds_dkv = 2 * NP * 128 + 2 * NP * 4;
-    static int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NP>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
-    static int attr2 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<NP>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
-    if (attr1 != 0) return attr1;
-    if (attr2 != 0) return attr2;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NP>), dim3(p.B * p.H), dim3(ATT_THREADS), lds_dq, s, p);
-    NRV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<NP>), dim3(p.B * p.H), dim3(ATT_THREADS), lds_dkv, s, p);
-    NRV_CHECK_LAUNCH();
-    return 0;
-}
-
 int check_shape(int B, int N, int H, int dh) {
     if (B <= 0 || N <= 0 || H <= 0) return NRV_ERR_SHAPE;
     if (dh != DH || N > 256) return NRV_ERR_SHAPE;
     if ((long long)B * H > 0x7fffffffll) return NRV_ERR_SHAPE;
     return 0;
 }
-
-#define NRV_DISPATCH_NP(N, CALL)                                   \
-    switch (((N) + 31) / 32) {                                     \
-        case 1: { constexpr int NPV = 32; return CALL; }           \
-        case 2: { constexpr int NPV = 64; return CALL; }           \
-        case 3: { constexpr int NPV = 96; return CALL; }           \
-        case 4: { constexpr int NPV = 128; return CALL; }          \
-        case 5: { constexpr int NPV = 160; return CALL; }          \
-        case 6: { constexpr int NPV = 192; return CALL; }          \
-        case 7: { constexpr int NPV = 224; return CALL; }          \
-        default: { constexpr int NPV = 256; return CALL; }         \
-    }
 
 }  // namespace
 
@@ -1084,11 +876,8 @@ extern "C" int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
     p.o = static_cast<bf16_t*>(out_bf16);
     p.lse = lse;
     p.B = B; p.N = N; p.H = H; p.scale = scale;
-    static const int dbg = [] { const char* e = getenv("NRV_ATTN_DBG"); return e ? atoi(e) : 0; }();
-    p.dbg = dbg;
-    p.stamps = (dbg & 4) ? attn_stamp_buffer() : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    NRV_DISPATCH_NP(N, launch_fwd<NPV>(p, s));
+    return launch_fwd_fat(p, s);
 }
 
 extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse,
@@ -1107,11 +896,5 @@ extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const vo
     p.delta = delta_ws;
     p.B = B; p.N = N; p.H = H; p.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    NRV_DISPATCH_NP(N, launch_bwd<NPV>(p, s));
-}
-
-extern "C" int nrv_debug_read_attn_stamps(unsigned long long* host_out, size_t count) {
-    unsigned long long* b = attn_stamp_buffer();
-    if (!b || !host_out || count * 8 > ATTN_STAMP_BYTES) return NRV_ERR_NULL;
-    return (int)hipMemcpy(host_out, b, count * 8, hipMemcpyDeviceToHost);
+    return launch_bwd_fat(p, s);
 }

@@ -3,6 +3,7 @@ same op evaluated on the SAME bf16-rounded operands (so the only differences are
 the final store rounding).  Tolerances are written next to each check.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -395,3 +396,15 @@ def test_errors_are_loud(dev):
     qkv = rnd((300, 3 * 64), dev, 2)
     with pytest.raises(NrvError):
         k.attn_fwd(qkv, 1, 300, 1, 64, 0.125)   # N > 256 unsupported
+
+
+def test_attention_bwd_fused_variant_in_child_process(dev):
+    """The single-kernel backward (NRV_ATTN_BWD_FUSED=1, opt-in) is selected when the library is first used, so it is
+    exercised in ONE child process that reruns the attention parity cases above."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NRV_ATTN_BWD_FUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
+                        "-k", "test_attention_fwd_bwd or test_attention_large_logits", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
