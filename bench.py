@@ -204,9 +204,8 @@ def main():
         _enc.set_overlap(False)
         with K.LaunchProfile() as prof:
             for _ in range(2):
-                trainer.forward_backward(x, y) if world == 1 else None
                 if world == 1:
-                    trainer.opt.zero_grad(set_to_none=True)
+                    trainer.forward_backward(x, y)      # gradients are overwritten in the flat buffer every step
         summ = prof.summary() if world == 1 else {}
         _enc.set_overlap(_overlap_was)
         if "gemm_nt" in summ:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 3
+#define NRV_ABI_VERSION 4
 
 /* dtype codes */
 #define NRV_F32 0
@@ -180,6 +180,23 @@ int nrv_gather_rows_f32(const float* src, const int64_t* index, float* out,
                         int64_t rows_out, int dim, void* stream);
 int nrv_scatter_rows_f32(const float* dout, const int64_t* index, float* dsrc,
                          int64_t rows_out, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step on flat fp32 buffers (replaces torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of the reference
+ * harness: examples/CIFAR100.py:90-97,191-192, baseline.py:127).
+ *   nrv_sumsq_f32 : out[0] = sum_i x[i]^2 (deterministic two-stage reduction; workspace nrv_sumsq_workspace(n) bytes)
+ *   nrv_adamw_f32 : for every i:  g = grad[i] * c,  c = min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6))  (c = 1 when gnorm_sq
+ *                   is NULL or max_norm <= 0);  p *= 1 - lr * weight_decay;  m = beta1 m + (1 - beta1) g;
+ *                   v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *                   -- torch.optim.AdamW (amsgrad = False, maximize = False) arithmetic, step >= 1.
+ *   Hyper-parameters are doubles (1 - beta and the bias corrections are formed in double, then rounded, as torch does).
+ *   p, grad, m, v: fp32 [n], 16-byte aligned; gnorm_sq: DEVICE pointer to one float (no host round trip).
+ * ---------------------------------------------------------------------------------------- */
+size_t nrv_sumsq_workspace(int64_t n);
+int nrv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int nrv_adamw_f32(float* p, const float* grad, float* m, float* v, int64_t n,
+                  double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                  const float* gnorm_sq, float max_norm, void* stream);
 
 /* Hardware-assumption probes used by tests/test_hw_probe.py (MFMA lane maps, transposed LDS read,
  * LDS-DMA layout and out-of-range zero fill).  out: fp32 scratch written by a single wave. */

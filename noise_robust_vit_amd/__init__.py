@@ -9,5 +9,15 @@ Importing this package does not need a GPU; running a forward does, and fails lo
 from .simple_vit import Attention, FeedForward, SimpleViT, SinkhornAttention, Transformer  # noqa: F401
 from .vit import VisionTransformer, vit_b_16, vit_b_32, vit_l_16, vit_l_32, vit_s_16  # noqa: F401
 
-__all__ = ["SimpleViT", "Attention", "FeedForward", "Transformer", "SinkhornAttention",
+
+
+def invalidate_weight_cache() -> None:
+    """Drop the bf16 images of the weights (encoder.WeightCache).  They are keyed on each parameter's autograd version
+    counter; call this after updating parameters by any means that does not bump it (raw-pointer kernels, some fused
+    multi-tensor optimizers).  `train.Trainer` and `optim.FusedAdamW` do it themselves."""
+    from .encoder import WEIGHTS
+    WEIGHTS.clear()
+
+
+__all__ = ["invalidate_weight_cache", "SimpleViT", "Attention", "FeedForward", "Transformer", "SinkhornAttention",
            "VisionTransformer", "vit_s_16", "vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32"]

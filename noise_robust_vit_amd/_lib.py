@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, c_double
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRV_LIB_PATH: developer override used to A/B kernel variants (tools/); the shipped path is the in-tree library
@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NRV_LIB_PATH") or _DEFAULT_LIB
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -53,6 +53,10 @@ SIGNATURES = {
     "nrv_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nrv_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "nrv_scatter_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "nrv_sumsq_workspace": (c_size_t, [c_int64]),
+    "nrv_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nrv_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                              c_double, c_double, c_double, c_double, c_double, c_int, c_void_p, c_float, c_void_p]),
     "nrv_probe": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p]),
 }
 

@@ -360,3 +360,31 @@ def probe(which: int, data: Tensor, n_out: int) -> Tensor:
     out = torch.zeros(n_out, dtype=torch.float32, device=data.device)
     check(_lib.load().nrv_probe(which, data.data_ptr(), out.data_ptr(), data.numel() * data.element_size(), _stream()), "nrv_probe")
     return out
+
+
+def sumsq_workspace(n: int) -> int:
+    return int(_lib.load().nrv_sumsq_workspace(int(n)))
+
+
+def sumsq(x: Tensor, out: Tensor, ws: Tensor) -> None:
+    """out[0] = sum(x^2) for a flat fp32 buffer (deterministic); ws: fp32 scratch of nrv_sumsq_workspace bytes."""
+    _f32(x, "x")
+    lib = _lib.load()
+    _run("optimizer", 0.0, x.numel() * 4,
+         lambda: lib.nrv_sumsq_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()),
+         "nrv_sumsq_f32")
+
+
+def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
+               weight_decay: float, step: int, gnorm_sq: Optional[Tensor], max_norm: float) -> None:
+    """In-place clip + AdamW on flat fp32 buffers (include/nrv.h: nrv_adamw_f32)."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _f32(t, n)
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise NrvError("adamw_flat: buffers differ in length")
+    lib = _lib.load()
+    _run("optimizer", 0.0, p.numel() * 28,
+         lambda: lib.nrv_adamw_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                   _ptr(gnorm_sq), float(max_norm), _stream()),
+         "nrv_adamw_f32")

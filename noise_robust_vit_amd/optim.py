@@ -1,0 +1,78 @@
+"""Fused optimizer step of the training harness: global-norm clipping + AdamW on flat fp32 buffers (csrc/nrv_optim.hip).
+
+Counterpart of what the reference harness runs after backward (examples/CIFAR100.py:90-97,191-192; baseline.py:127):
+`torch.nn.utils.clip_grad_norm_(params, 5.0)` followed by `torch.optim.AdamW(...).step()`.  The arithmetic is
+torch.optim.AdamW's (pinned against it in tests/test_optim_gpu.py); the layout is this build's:
+
+  * gradients already live in ONE flat fp32 buffer (`parallel.GradReducer.flat`, backward order, 16-byte slots);
+  * parameters are moved into a second flat buffer with the SAME slot layout (each `param.data` becomes a view, so
+    `state_dict()` / checkpoints are unchanged), Adam moments are two more;
+  * one step = `nrv_sumsq_f32` over the gradient buffer + `nrv_adamw_f32` over all four: ~32 B/parameter of HBM traffic
+    and 3 launches instead of PyTorch's ~6 multi-tensor launches over 150 tensors; the clip coefficient never visits the host.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import kernels as K
+from ._lib import NrvError
+
+
+class FusedAdamW:
+    def __init__(self, reducer, lr: float, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        if not reducer.flat.is_cuda:
+            raise NrvError("FusedAdamW runs on the MI355X only (flat gradient buffer is not a HIP tensor)")
+        self.reducer = reducer
+        self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), (float(betas[0]), float(betas[1])), float(eps)
+        self.grad = reducer.flat
+        dev = self.grad.device
+        self.param = torch.zeros_like(self.grad)
+        self._views: Dict[int, torch.Tensor] = {}
+        for p in reducer.parameters():
+            o, n = reducer.slot(p)
+            view = self.param[o:o + n].view(p.shape)
+            with torch.no_grad():
+                view.copy_(p.data)
+            p.data = view                                   # the module now reads / writes the flat buffer
+            self._views[id(p)] = view
+        self.exp_avg = torch.zeros_like(self.grad)
+        self.exp_avg_sq = torch.zeros_like(self.grad)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ws = torch.empty(max(K.sumsq_workspace(self.grad.numel()) // 4, 4), dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    def _check_layout(self) -> None:
+        for p in self.reducer.parameters():
+            if p.data_ptr() != self._views[id(p)].data_ptr():
+                raise NrvError("a parameter was re-allocated after FusedAdamW was built (e.g. model.to(...)): "
+                               "build the optimizer after the model is on its device")
+
+    def step(self, max_norm: float = 0.0, lr: float = None) -> None:
+        """One AdamW step on every parameter; max_norm > 0 clips the global gradient norm first (clip_grad_norm_)."""
+        if self.step_count == 0:
+            self._check_layout()
+        self.step_count += 1
+        if max_norm and max_norm > 0:
+            K.sumsq(self.grad, self.gnorm_sq, self._ws)
+        K.adamw_flat(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
+                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                     self.gnorm_sq if max_norm and max_norm > 0 else None, float(max_norm or 0.0))
+        # the parameters changed through raw pointers: their version counters did not move, so the bf16 weight images
+        # (encoder.WeightCache, keyed on the version) are dropped explicitly
+        from .encoder import WEIGHTS
+        WEIGHTS.clear()
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global gradient norm seen by the last clipped step (device scalar; reading it synchronises)."""
+        return self.gnorm_sq.sqrt()
+
+    def state_dict(self) -> dict:
+        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -79,6 +79,14 @@ class GradReducer:
             model.attach_grad_sink(self)
         self.begin_step()
 
+    def parameters(self):
+        """The trainable parameters, registration order."""
+        return list(self._params)
+
+    def slot(self, p: torch.Tensor):
+        """(offset, numel) of p's gradient in `flat` (optim.FusedAdamW lays its parameter / moment buffers out the same way)."""
+        return self._slot[id(p)]
+
     # ---- sink interface used by encoder.py ---------------------------------------------------
     def target(self, p: torch.Tensor):
         """Where a kernel should write d(loss)/d(p) this step, and the beta to use (0: overwrite)."""

@@ -10,8 +10,9 @@ What the reference harness does per step and this module reproduces (file:line i
   * per-iteration LinearLR(1e-3 -> 1) warm-up over 10 % of the epochs, then cosine to 0.05 lr   CIFAR100.py:99-113,165-166
   * DDP: gradients averaged over ranks (all-reduce SUM / world) before the optimizer step
 
-The optimizer / clip / schedule arithmetic is PyTorch-ROCm's (`torch.optim.AdamW(fused=True)`): SURVEY.md §8f rank 3
-marks a hand-written fused optimizer as "next", not part of the encoder hot path.
+On the MI355X the clip + AdamW arithmetic runs in `optim.FusedAdamW` (two HBM-bound HIP kernels over flat buffers,
+SURVEY.md §8f rank 3); with CPU tensors (the gloo tests of the data-parallel logic) it is `torch.optim.AdamW`, whose
+arithmetic the HIP kernels are pinned against (tests/test_optim_gpu.py).
 """
 from __future__ import annotations
 
@@ -66,12 +67,21 @@ class Trainer:
     """One process per GPU.  `reducer` (parallel.GradReducer) is None for single-GPU runs."""
 
     def __init__(self, model: torch.nn.Module, cfg: TrainConfig, reducer=None) -> None:
-        self.model, self.cfg, self.reducer = model, cfg, reducer
+        self.model, self.cfg = model, cfg
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params
-        fused = all(p.is_cuda for p in params)
-        self.opt = torch.optim.AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay, eps=1e-8, betas=(0.9, 0.999),
-                                     fused=fused)
+        on_gpu = all(p.is_cuda for p in params)
+        if on_gpu and reducer is None:
+            # single GPU: the reducer is still what keeps all gradients in one flat buffer (it launches no collective)
+            from .parallel import GradReducer
+            reducer = GradReducer(model, 1)
+        self.reducer = reducer
+        if on_gpu:
+            from .optim import FusedAdamW
+            self.opt = FusedAdamW(reducer, lr=cfg.lr, weight_decay=cfg.weight_decay, betas=(0.9, 0.999), eps=1e-8)
+        else:
+            self.opt = torch.optim.AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay, eps=1e-8, betas=(0.9, 0.999))
+        self.fused = on_gpu
         self.step_idx = 0
         self.rng = np.random.default_rng(cfg.seed)
 
@@ -104,15 +114,21 @@ class Trainer:
 
     def optimizer_step(self) -> None:
         c = self.cfg
-        if c.grad_max_norm and c.grad_max_norm > 0:
-            torch.nn.utils.clip_grad_norm_(self.params, c.grad_max_norm, foreach=True)
-        if c.warmup_steps or c.cosine_steps:
-            lr = warmup_cosine_lr(self.step_idx, c.lr, c.warmup_steps, c.cosine_steps)
+        lr = warmup_cosine_lr(self.step_idx, c.lr, c.warmup_steps, c.cosine_steps) if (c.warmup_steps or c.cosine_steps) else c.lr
+        if self.fused:
+            self.opt.step(max_norm=c.grad_max_norm or 0.0, lr=lr)
+        else:
+            if c.grad_max_norm and c.grad_max_norm > 0:
+                torch.nn.utils.clip_grad_norm_(self.params, c.grad_max_norm, foreach=True)
             for g in self.opt.param_groups:
                 g["lr"] = lr
-        self.opt.step()
-        if self.reducer is None:
-            self.opt.zero_grad(set_to_none=True)
+            self.opt.step()
+            # do not rely on the optimizer bumping the parameters' version counters (torch's fused multi-tensor AdamW on
+            # ROCm was seen not to: the bf16 weight images then went stale): drop them explicitly
+            from .encoder import WEIGHTS
+            WEIGHTS.clear()
+            if self.reducer is None:
+                self.opt.zero_grad(set_to_none=True)
         self.step_idx += 1
 
     def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
