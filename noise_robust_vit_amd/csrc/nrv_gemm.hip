@@ -368,25 +368,21 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 }
 
 // ---------------------------------------------------------------------------------------------
-// NT kernel, deep-ring variant: same 256x256 tile and wave layout, but the K dimension is streamed in 32-deep
-// half-steps through a ring of FOUR 32 KiB stages (16 KiB A + 16 KiB B) with counted vmcnt: three half-steps
-// (96 KiB) are in flight while the fourth is multiplied, instead of one 64 KiB stage.  The main loop of the 2-stage
-// kernel is LDS-DMA *latency* bound, so bytes in flight per CU is the lever.
+// NT kernel, deep-ring variant: same 256x256 tile and wave layout, but K is streamed in 32-deep HALF-steps through a
+// ring of FOUR 32 KiB LDS slots (16 KiB A + 16 KiB B), and the MFMA operands are double-buffered in REGISTERS:
+//     half-step s:   wait (counted) for slot s+1   |  barrier  |  DMA of half-step s+4 -> the slot half-step s just left
+//                    12 ds_read_b128 of half-step s+1 -> fragment set B, sprinkled between the
+//                    32 MFMAs of half-step s from fragment set A (read during half-step s-1)
+// so (1) a DMA has three half-steps (1.5 K-steps of MFMA time) to land instead of half a K-step -- the 2-stage kernel
+// above stalls on vmcnt(0) every K-step, it is LDS-DMA *latency* bound --, (2) the fragment reads of a
+// half-step are never waited for inside it, and (3) the barrier has MFMAs queued on both sides.
 // LDS image: [256 rows][32 k] bf16 = 64-byte rows; chunk c (0..3) of row r sits at position c ^ G[(r >> 2) & 3],
 // G = {0, 3, 2, 1}: conflict-free ds_read_b128 for the fragment pattern (4 rows share a 256-byte bank row).
+// vmcnt bookkeeping: 4 DMA instructions per wave per half-step, no other vector-memory instruction inside the loop.
 // ---------------------------------------------------------------------------------------------
 constexpr int R_BK = 32, R_NST = 4, R_STAGE = 32768, R_B_OFF = 16384, R_LDS = R_NST * R_STAGE;
 
 __device__ __forceinline__ int ring_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
-
-__device__ __forceinline__ void wait_vmcnt_rt(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ring_kernel(const GemmNTParams p) {
@@ -423,15 +419,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ring_kernel(const Gem
         st_b[i] = (n0 + r < N) ? (unsigned)((long long)r * p.ldb * 2) + c * 16 : NRV_OOB;
     }
     const int nk = (K + R_BK - 1) / R_BK;
-    auto stage = [&](int s) {           // 4 DMA instructions per thread
+    // one of the 4 DMA instructions of half-step s (d = 0,1: A rows; 2,3: B rows)
+    auto dma_one = [&](int s, int d) {
         char* base = smem + (s & (R_NST - 1)) * R_STAGE;
         const int k0 = s * R_BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool kok = (k0 + st_k[i]) < K;
-            dma16(ra, base + (i * 8 + wave) * 1024, (kok && st_a[i] != NRV_OOB) ? st_a[i] + k0 * 2 : NRV_OOB);
-            dma16(rb, base + R_B_OFF + (i * 8 + wave) * 1024, (kok && st_b[i] != NRV_OOB) ? st_b[i] + k0 * 2 : NRV_OOB);
-        }
+        const int i = d & 1;
+        const bool kok = (k0 + st_k[i]) < K;
+        if (d < 2) dma16(ra, base + (i * 8 + wave) * 1024, (kok && st_a[i] != NRV_OOB) ? st_a[i] + k0 * 2 : NRV_OOB);
+        else dma16(rb, base + R_B_OFF + (i * 8 + wave) * 1024, (kok && st_b[i] != NRV_OOB) ? st_b[i] + k0 * 2 : NRV_OOB);
     };
 
     const int fr = lane & 15, fg = lane >> 4;
@@ -445,29 +440,60 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ring_kernel(const Gem
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // two fragment sets (A: 8 row tiles, B: 4 column tiles of one 32-deep half-step)
+    bf16x8_t fa0[8], fb0[4], fa1[8], fb1[4];
+    auto read_frags = [&](int s, bf16x8_t (&fa)[8], bf16x8_t (&fb)[4], int mi) {      // the reads that accompany row tile mi
+        const char* sa = smem + (s & (R_NST - 1)) * R_STAGE;
+        fa[mi] = lds_read_b128(sa + (a_rd + mi * 1024));
+        if (mi < 4) fb[mi] = lds_read_b128(sa + (b_rd + mi * 1024));
+    };
+
+    // prologue: half-steps 0..3 in flight, wait for 0, read its fragments
 #pragma unroll
-    for (int s = 0; s < R_NST - 1; ++s)
-        if (s < nk) stage(s);
-    for (int s = 0; s < nk; ++s) {
-        // younger than the DMA group of half-step s: the groups of s+1 and s+2 (4 instructions each) if they exist
-        const int younger = (s + 2 < nk ? 8 : (s + 1 < nk ? 4 : 0));
-        wait_vmcnt_rt(younger);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int s = 0; s < R_NST; ++s)
+        if (s < nk) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dma_one(s, d);
+        }
+    {
+        const int younger = (nk > 3 ? 12 : (nk > 2 ? 8 : (nk > 1 ? 4 : 0)));
+        switch (younger) {
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + R_NST - 1 < nk) stage(s + R_NST - 1);        // slot (s + 3) & 3 == (s - 1) & 3: read in the previous half-step
-        const char* sa = smem + (s & (R_NST - 1)) * R_STAGE;
-        bf16x8_t bfr[4], af[2];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bfr[ni] = lds_read_b128(sa + (b_rd + ni * 1024));
-        af[0] = lds_read_b128(sa + a_rd);
+        for (int mi = 0; mi < 8; ++mi) read_frags(0, fa0, fb0, mi);
+    }
+
+    // one half-step: MFMAs of s from (fa, fb); fragments of s+1 into (na, nb); DMA of s+4
+    auto half_step = [&](int s, bf16x8_t (&fa)[8], bf16x8_t (&fb)[4], bf16x8_t (&na)[8], bf16x8_t (&nb)[4]) {
+        const bool has_next = s + 1 < nk;
+        // slot s+1 must have landed: younger DMA groups are those of s+2, s+3 (s+4 is issued below)
+        const int younger = (s + 3 < nk ? 8 : (s + 2 < nk ? 4 : 0));
+        if (younger == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (younger == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                   // (guide rule 18: keep the MFMAs behind the wait)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = s + R_NST < nk;                    // slot s & 3 was read during half-step s-1: free now
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
-            if (mi + 1 < 8) af[(mi + 1) & 1] = lds_read_b128(sa + (a_rd + (mi + 1) * 1024));
+            if (has_next) read_frags(s + 1, na, nb, mi);
+            if (more && mi < 4) dma_one(s + R_NST, mi);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bfr[ni], af[mi & 1], acc[mi][ni]);
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
         }
+    };
+    for (int s = 0; s < nk; s += 2) {
+        half_step(s, fa0, fb0, fa1, fb1);
+        if (s + 1 < nk) half_step(s + 1, fa1, fb1, fa0, fb0);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     epilogue<EPI, OUT_F32, AUX_F32, 8>(acc, smem, p.e, m0 + wr * 128, n0 + wc * 64, lane, wave);     // ring is idle: reuse it
 }
