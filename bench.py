@@ -66,8 +66,9 @@ def pmc_traffic(kernel_class: str):
         return None
 
 
-def cpu_baseline(arch: str, seconds_budget: float = 15.0):
-    """Reference-algorithm CPU path (oracle port: fp32 forward + autograd backward + CE) on the host cores."""
+def cpu_baseline(arch: str, seconds_budget: float = 12.0):
+    """Reference-algorithm CPU path (oracle port: fp32 forward + autograd backward + CE) on the host cores: a bounded sample
+    of the same workload -- batch 4 steps repeated for ~12 s of CPU work."""
     from oracle import simple_vit_oracle as SO
     from oracle import vit_oracle as VO
     kind, kw, _ = ARCHS[arch]
@@ -102,7 +103,7 @@ def cpu_baseline(arch: str, seconds_budget: float = 15.0):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 4:
+        if el > seconds_budget or n >= 64:
             break
     return {"value": round(batch * n / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{arch} fp32 forward+CE+backward (oracle/), batch {batch}, {n} timed steps after 1 warm-up, "
