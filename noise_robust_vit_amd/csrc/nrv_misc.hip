@@ -53,27 +53,54 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(const void* __restric
 // ---------------------------------------------------------------------------------------------
 // weight staging: w fp32 [R,C] -> wb bf16 [R,C], wt bf16 [C,R]
 // ---------------------------------------------------------------------------------------------
+// 64 x 64 tile per workgroup: 16-byte fp32 loads (256 contiguous bytes per 16 lanes), 8-byte bf16 stores for both the
+// straight and the transposed copy (the 32 x 32 / 2-byte-store version ran at 2.7 TB/s and cost 0.34 ms per optimizer step).
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb,
                                                              bf16_t* __restrict__ wt, long long R, long long C) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
-    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 x 16
+    const long long c0 = (long long)blockIdx.x * 64, r0 = (long long)blockIdx.y * 64;
+    const bool vec_ok = (C & 3) == 0;                            // rows stay 16-byte aligned
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const long long r = r0 + ty + 8 * k, c = c0 + tx;
-        float v = 0.f;
-        if (r < R && c < C) {
-            v = w[r * C + c];
-            wb[r * C + c] = f32_to_bf16(v);
+        const long long r = r0 + ty + 16 * k, c = c0 + 4 * tx;
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+            if (vec_ok && c + 3 < C) {
+                v = *reinterpret_cast<const f32x4_t*>(w + r * C + c);
+                u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2_t*>(wb + r * C + c) = pk;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < C) {
+                        v[j] = w[r * C + c + j];
+                        wb[r * C + c + j] = f32_to_bf16(v[j]);
+                    }
+            }
         }
-        tile[ty + 8 * k][tx] = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[ty + 16 * k][4 * tx + j] = v[j];
     }
     if (wt == nullptr) return;
     __syncthreads();
+    const bool vec_t = (R & 3) == 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const long long c = c0 + ty + 8 * k, r = r0 + tx;
-        if (r < R && c < C) wt[c * R + r] = f32_to_bf16(tile[tx][ty + 8 * k]);
+        const long long c = c0 + ty + 16 * k, r = r0 + 4 * tx;      // output row c of wt, columns r .. r + 3
+        if (c < C) {
+            const float a0 = tile[4 * tx + 0][ty + 16 * k], a1 = tile[4 * tx + 1][ty + 16 * k];
+            const float a2 = tile[4 * tx + 2][ty + 16 * k], a3 = tile[4 * tx + 3][ty + 16 * k];
+            if (vec_t && r + 3 < R) {
+                u32x2_t pk = {pack_bf16x2(a0, a1), pack_bf16x2(a2, a3)};
+                *reinterpret_cast<u32x2_t*>(wt + c * R + r) = pk;
+            } else {
+                const float a[4] = {a0, a1, a2, a3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r + j < R) wt[c * R + r + j] = f32_to_bf16(a[j]);
+            }
+        }
     }
 }
 
@@ -189,9 +216,9 @@ extern "C" int nrv_patch_unfold(const void* img, int img_dtype, void* patches_bf
 
 extern "C" int nrv_cast_transpose(const float* w, void* w_bf16, void* wT_bf16, int64_t R, int64_t C, void* stream) {
     if (!w || !w_bf16) return NRV_ERR_NULL;
-    if (R <= 0 || C <= 0 || R > 0x7fffffll * 32 || C > 0x7fffffll * 32) return NRV_ERR_SHAPE;
+    if (R <= 0 || C <= 0 || R > 0xffffll * 64 || C > 0x7fffffll * 64) return NRV_ERR_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)nrv_cdiv(C, 32), (unsigned)nrv_cdiv(R, 32)), dim3(256), 0, s,
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)nrv_cdiv(C, 64), (unsigned)nrv_cdiv(R, 64)), dim3(256), 0, s,
                        w, static_cast<bf16_t*>(w_bf16), static_cast<bf16_t*>(wT_bf16), (long long)R, (long long)C);
     NRV_CHECK_LAUNCH();
     return 0;

@@ -360,7 +360,7 @@ def test_patch_unfold(dev, layout, dt):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("R,C", [(192, 576), (768, 3072), (100, 72), (1000, 192)])
+@pytest.mark.parametrize("R,C", [(192, 576), (768, 3072), (100, 72), (1000, 192), (37, 50), (64, 64), (130, 6), (3, 257)])
 def test_cast_transpose(dev, R, C):
     k = _k()
     w = rnd((R, C), dev, 80, 1.0, torch.float32)
