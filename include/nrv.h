@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 4
+#define NRV_ABI_VERSION 5
 
 /* dtype codes */
 #define NRV_F32 0
@@ -169,6 +169,19 @@ int nrv_patch_unfold(const void* img, int img_dtype, void* patches_bf16,
 
 /* Weight staging: w fp32 [R,C] -> w_bf16 [R,C] and (optional) wT_bf16 [C,R]; once per optimizer step. */
 int nrv_cast_transpose(const float* w, void* w_bf16, void* wT_bf16, int64_t R, int64_t C, void* stream);
+
+/* The same for many matrices in one launch.  jobs_dev: DEVICE array of njobs entries, sorted by tile_start;
+ * a matrix of R x C occupies ceil(R/64) * ceil(C/64) consecutive tile numbers starting at tile_start (tiles_c =
+ * ceil(C/64)); total_tiles = the sum.  wT_bf16 may be NULL per job.  The caller fills the table (host-side arithmetic only). */
+typedef struct nrv_cast_job {
+    const float* w;
+    void* w_bf16;
+    void* wT_bf16;
+    int64_t R, C;
+    int64_t tile_start;
+    int64_t tiles_c;
+} nrv_cast_job;
+int nrv_cast_transpose_batched(const nrv_cast_job* jobs_dev, int njobs, int64_t total_tiles, void* stream);
 
 /* Elementwise cast fp32 -> bf16 (n % 8 == 0 not required). */
 int nrv_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream);

@@ -44,6 +44,7 @@ class WeightCache:
 
     def __init__(self) -> None:
         self._d = {}
+        self._jobs = None
 
     def get(self, w: Tensor, need_t: bool):
         key = id(w)
@@ -58,10 +59,33 @@ class WeightCache:
         if len(self._d) > 2048:
             self._d = {k: v for k, v in self._d.items() if v[0]() is not None}
         self._d[key] = (weakref.ref(w), ver, w.data_ptr(), wb, wt)
+        self._jobs = None
         return wb, wt
 
     def clear(self) -> None:
         self._d.clear()
+        self._jobs = None
+
+    def refresh_all(self) -> None:
+        """Re-stage every live entry IN PLACE with one batched launch (after an optimizer step that updated the fp32 masters
+        through raw pointers: version counters and addresses are unchanged, so the entries stay valid afterwards)."""
+        live = [(k, v) for k, v in self._d.items() if v[0]() is not None]
+        if len(live) != len(self._d):
+            self._d = dict(live)
+            self._jobs = None
+        key = tuple(k for k, _ in live)
+        jobs = getattr(self, "_jobs", None)
+        if jobs is None or jobs[0] != key:
+            srcs = []
+            for _, (ref, ver, ptr, wb, wt) in live:
+                w = ref().detach()
+                if w.data_ptr() != ptr or w._version != ver or not w.is_contiguous():
+                    self.clear()                 # something else changed: fall back to lazy re-staging
+                    return
+                srcs.append((w.reshape(wb.shape), wb, wt))
+            jobs = (key, K.build_cast_jobs(srcs), srcs)
+            self._jobs = jobs
+        K.run_cast_jobs(jobs[1])
 
 
 WEIGHTS = WeightCache()

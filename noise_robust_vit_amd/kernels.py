@@ -388,3 +388,38 @@ def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: flo
                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                                    _ptr(gnorm_sq), float(max_norm), _stream()),
          "nrv_adamw_f32")
+
+
+def cast_transpose_batched(jobs) -> None:
+    """Re-stage many weights in ONE launch.  jobs: list of (w fp32 [R,C], wb bf16 [R,C], wt bf16 [C,R] | None), all on one device;
+    returns a reusable handle via `build_cast_jobs`."""
+    handle = build_cast_jobs(jobs)
+    run_cast_jobs(handle)
+
+
+def build_cast_jobs(jobs):
+    """Device-side job table of include/nrv.h `nrv_cast_job` (7 x int64 per entry).  The tensors must stay alive (and in place)
+    for as long as the handle is used."""
+    import numpy as np
+    if not jobs:
+        return None
+    rows, start = [], 0
+    for w, wb, wt in jobs:
+        _f32(w, "w"); _bf16(wb, "wb")
+        if not (w.is_contiguous() and wb.is_contiguous() and (wt is None or wt.is_contiguous())):
+            raise NrvError("cast jobs need contiguous tensors")
+        R, C = w.shape
+        tiles_c = (C + 63) // 64
+        rows.append((w.data_ptr(), wb.data_ptr(), 0 if wt is None else wt.data_ptr(), R, C, start, tiles_c))
+        start += ((R + 63) // 64) * tiles_c
+    table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(jobs[0][0].device)
+    return table, len(rows), start
+
+
+def run_cast_jobs(handle) -> None:
+    if handle is None:
+        return
+    table, n, total = handle
+    lib = _lib.load()
+    _run("cast_transpose", 0.0, 0.0, lambda: lib.nrv_cast_transpose_batched(table.data_ptr(), n, total, _stream()),
+         "nrv_cast_transpose_batched")

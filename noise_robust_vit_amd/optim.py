@@ -60,9 +60,9 @@ class FusedAdamW:
                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                      self.gnorm_sq if max_norm and max_norm > 0 else None, float(max_norm or 0.0))
         # the parameters changed through raw pointers: their version counters did not move, so the bf16 weight images
-        # (encoder.WeightCache, keyed on the version) are dropped explicitly
+        # (encoder.WeightCache, keyed on the version) are re-staged explicitly -- all of them in one batched launch
         from .encoder import WEIGHTS
-        WEIGHTS.clear()
+        WEIGHTS.refresh_all()
 
     def grad_norm(self) -> torch.Tensor:
         """Global gradient norm seen by the last clipped step (device scalar; reading it synchronises)."""

@@ -408,3 +408,19 @@ def test_attention_bwd_fused_variant_in_child_process(dev):
                         "-k", "test_attention_fwd_bwd or test_attention_large_logits", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cast_transpose_batched_matches_single(dev):
+    k = _k()
+    shapes = [(768, 768), (100, 72), (37, 50), (2304, 768), (3, 257), (64, 64)]
+    ws = [rnd(s, dev, 90 + i, 1.0, torch.float32) for i, s in enumerate(shapes)]
+    jobs = []
+    for i, w in enumerate(ws):
+        wb = torch.full(w.shape, 7.0, dtype=torch.bfloat16, device=dev)
+        wt = None if i == 1 else torch.full((w.shape[1], w.shape[0]), 7.0, dtype=torch.bfloat16, device=dev)
+        jobs.append((w, wb, wt))
+    k.cast_transpose_batched(jobs)
+    for w, wb, wt in jobs:
+        assert torch.equal(wb, w.to(torch.bfloat16))
+        if wt is not None:
+            assert torch.equal(wt, w.to(torch.bfloat16).t().contiguous())
