@@ -28,7 +28,7 @@ import torch.nn.functional as F
 def warmup_cosine_lr(step: int, base_lr: float, warmup_steps: int, cosine_steps: int,
                      start_factor: float = 1e-3, eta_min_ratio: float = 0.05) -> float:
     """Closed form of SequentialLR([LinearLR(start_factor, 1, T1), CosineAnnealingLR(T2, eta_min=0.05 lr)], [T1])
-    stepped once per iteration (CIFAR100.py:99-113).  Pinned against torch.optim.lr_scheduler in tests/test_train_host.py."""
+    stepped once per iteration (CIFAR100.py:99-113).  Pinned against torch.optim.lr_scheduler in tests/test_host_logic.py."""
     if warmup_steps > 0 and step < warmup_steps:
         return base_lr * (start_factor + (1.0 - start_factor) * step / warmup_steps)
     t = step - warmup_steps
