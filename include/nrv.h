@@ -211,7 +211,7 @@ int nrv_adamw_f32(float* p, const float* grad, float* m, float* v, int64_t n,
                   double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                   const float* gnorm_sq, float max_norm, void* stream);
 
-/* Hardware-assumption probes used by tests/test_hw_probe.py (MFMA lane maps, transposed LDS read,
+/* Hardware-assumption probes used by tests/test_kernels_gpu.py (test_probe_*) (MFMA lane maps, transposed LDS read,
  * LDS-DMA layout and out-of-range zero fill).  out: fp32 scratch written by a single wave. */
 int nrv_probe(int which, const void* in, void* out, int n, void* stream);
 
