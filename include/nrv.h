@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 5
+#define NRV_ABI_VERSION 6
 
 /* dtype codes */
 #define NRV_F32 0
@@ -143,9 +143,14 @@ int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const void* dout_bf
                  void* dqkv_bf16, float* delta_ws,
                  int B, int N, int H, int dh, float scale, void* stream);
 
+/* Introspection only (Recorder-style attention maps, recorder.py:24-31; never on the training path):
+ *   probs fp32 [B, H, N, N] = exp(scale * q.k - lse), i.e. the softmax the fused kernels keep on chip. */
+int nrv_attn_probs(const void* qkv_bf16, const float* lse, float* probs,
+                   int B, int N, int H, int dh, float scale, void* stream);
+
 /* "robust" attention (robust=True): softmax followed by Sinkhorn normalisation -- 3 x (row /, column /) and a final
  * row / -- utils.py:1025-1037, wired at simple_vit.py:56-57.  Same layouts as nrv_attn_fwd.
- *   scalings fp32 [B, H, 7, N]: the row / column scaling vectors a1 b1 a2 b2 a3 b3 a4 (P = diag(a) softmax(S) diag(b)),
+ *   scalings fp32 [B, H, 7, N]: the row / column scaling vectors a1 b1 a2 b2 a3 b3 a4 (cumulative: after step t, P = diag(a_t) softmax(S) diag(b_t); the final matrix is diag(a4) softmax(S) diag(b3)),
  *   saved with lse for the backward.  dh == 64, N <= 256.
  *   Backward scratch: nrv_attn_sinkhorn_bwd_workspace(B, N, H) bytes (bf16 dS^T and P^T per head). */
 int nrv_attn_sinkhorn_fwd(const void* qkv_bf16, void* out_bf16, float* lse, float* scalings,

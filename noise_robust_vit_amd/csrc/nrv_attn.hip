@@ -857,6 +857,39 @@ int launch_bwd_fat(const AttnParams& p, hipStream_t s) {
     return launch_bwd_fat_nt<16>(p, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// introspection (Recorder-style attention maps, recorder.py:24-31): P[b,h,q,k] = exp(scale q.k - lse[b,h,q]) written out
+// in fp32.  NOT on the training path (which never materialises P): a plain VALU kernel, 16 queries per workgroup, the 16
+// query rows in LDS as fp32, one (query, key) dot product of 64 per thread and step.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
+                                                         float* __restrict__ probs, int B, int N, int H, float scale) {
+    __shared__ float qs[16][DH + 1];
+    const int bh = blockIdx.x, q0 = blockIdx.y * 16;
+    const int b = bh / H, h = bh - b * H;
+    const long long ldq = 3ll * H * DH;
+    const bf16_t* base = qkv + (long long)b * N * ldq + h * DH;
+    for (int i = threadIdx.x; i < 16 * DH; i += 256) {
+        const int r = i / DH, d = i - r * DH;
+        qs[r][d] = (q0 + r < N) ? bf16_to_f32(base[(long long)(q0 + r) * ldq + d]) : 0.f;
+    }
+    __syncthreads();
+    const int qi = threadIdx.x & 15;
+    const int q = q0 + qi;
+    const float l = q < N ? lse[((long long)b * H + h) * N + q] : 0.f;
+    for (int key = threadIdx.x >> 4; key < N; key += 16) {
+        const bf16_t* kp = base + H * DH + (long long)key * ldq;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            const bf16x8_t kv = load_frag_global(kp + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[qi][c * 8 + e], bf16_to_f32((unsigned short)kv[e]), acc);
+        }
+        if (q < N) probs[(((long long)b * H + h) * N + q) * N + key] = __expf(acc * scale - l);
+    }
+}
+
 int check_shape(int B, int N, int H, int dh) {
     if (B <= 0 || N <= 0 || H <= 0) return NRV_ERR_SHAPE;
     if (dh != DH || N > 256) return NRV_ERR_SHAPE;
@@ -897,4 +930,16 @@ extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const vo
     p.B = B; p.N = N; p.H = H; p.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return launch_bwd_fat(p, s);
+}
+
+extern "C" int nrv_attn_probs(const void* qkv_bf16, const float* lse, float* probs,
+                              int B, int N, int H, int dh, float scale, void* stream) {
+    if (!qkv_bf16 || !lse || !probs) return NRV_ERR_NULL;
+    if (int e = check_shape(B, N, H, dh)) return e;
+    if (!nrv_aligned16(qkv_bf16)) return NRV_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)(B * H), (unsigned)((N + 15) / 16)), dim3(256), 0, s,
+                       static_cast<const bf16_t*>(qkv_bf16), lse, probs, B, N, H, scale);
+    NRV_CHECK_LAUNCH();
+    return 0;
 }

@@ -166,6 +166,40 @@ def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Te
 
 
 # ----------------------------------------------------------------------------------------------
+# introspection: attention maps for recorder.Recorder (the fused kernels never materialise them)
+# ----------------------------------------------------------------------------------------------
+_RECORDING: Optional[list] = None
+
+
+class record_attention:
+    """Context manager: every attention layer run inside appends its fp32 [B, H, N, N] probabilities to `sink`
+    (softmax, or the Sinkhorn-normalised matrix for robust=True), recomputed from q, k and the saved statistics."""
+
+    def __init__(self, sink: list) -> None:
+        self.sink = sink
+
+    def __enter__(self):
+        global _RECORDING
+        self._prev, _RECORDING = _RECORDING, self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        global _RECORDING
+        _RECORDING = self._prev
+
+
+def _record(qkv: Tensor, aux, B: int, N: int, H: int, dh: int, scale: float, robust: bool) -> None:
+    if robust:
+        lse, scal = aux                                   # scalings [B, H, 7, N]: a1 b1 a2 b2 a3 b3 a4
+        p = K.attn_probs(qkv, lse, B, N, H, dh, scale)
+        a, b = scal[:, :, 6], scal[:, :, 5]              # the vectors are cumulative: P = diag(a4) softmax(S) diag(b3)
+        p = p * a[..., :, None] * b[..., None, :]
+    else:
+        p = K.attn_probs(qkv, aux, B, N, H, dh, scale)
+    _RECORDING.append(p)
+
+
+# ----------------------------------------------------------------------------------------------
 # attention half
 # ----------------------------------------------------------------------------------------------
 def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool):
@@ -182,6 +216,8 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
         o, aux = sinkhorn.attn_fwd(qkv, B, N, H, dh, scale)
     else:
         o, aux = K.attn_fwd(qkv, B, N, H, dh, scale)
+    if _RECORDING is not None:
+        _record(qkv, aux, B, N, H, dh, scale, meta.robust)
     if residual:
         y = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bo, aux=x)
     else:

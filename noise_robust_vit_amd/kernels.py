@@ -269,6 +269,15 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int
     return dqkv
 
 
+def attn_probs(qkv: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+    """fp32 [B, H, N, N] softmax probabilities recomputed from q, k and the saved log-sum-exp (introspection only)."""
+    _bf16(qkv, "qkv"); _f32(lse, "lse")
+    probs = torch.empty(B, H, N, N, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().nrv_attn_probs(qkv.data_ptr(), lse.data_ptr(), probs.data_ptr(), B, N, H, dh, float(scale), _stream()),
+          "nrv_attn_probs")
+    return probs
+
+
 def attn_sinkhorn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
     """robust=True attention (utils.py:1025-1037): returns (out bf16, lse fp32 [B,H,N], scalings fp32 [B,H,7,N])."""
     _bf16(qkv, "qkv")

@@ -424,3 +424,24 @@ def test_cast_transpose_batched_matches_single(dev):
         assert torch.equal(wb, w.to(torch.bfloat16))
         if wt is not None:
             assert torch.equal(wt, w.to(torch.bfloat16).t().contiguous())
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 49, 2), (1, 256, 1), (2, 5, 1)])
+def test_attention_probs_export(dev, B, N, H):
+    """nrv_attn_probs (introspection): exp(scale q.k - lse) equals torch.softmax on the same bf16 q, k; for the Sinkhorn
+    kernel the saved scalings turn it into the reference's normalised matrix (sinkhorn_ref)."""
+    k = _k()
+    dh = 64
+    scale = dh ** -0.5
+    qkv = rnd((B * N, 3 * H * dh), dev, 70, 1.0)
+    _, lse = k.attn_fwd(qkv, B, N, H, dh, scale)
+    p = k.attn_probs(qkv, lse, B, N, H, dh, scale)
+    q, kk, _ = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    ref = torch.softmax((q @ kk.transpose(-1, -2)) * scale, dim=-1)
+    assert (p - ref).abs().max().item() < 2e-5
+    _, lse_s, scal = k.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
+    ps = k.attn_probs(qkv, lse_s, B, N, H, dh, scale)
+    a, b = scal[:, :, 6], scal[:, :, 5]              # cumulative scalings: P = diag(a4) softmax(S) diag(b3)
+    ps = ps * a[..., :, None] * b[..., None, :]
+    _, pref = sinkhorn_ref(qkv, B, N, H, dh, scale)
+    assert (ps - pref).abs().max().item() < 1e-4 * max(1.0, pref.abs().max().item())

@@ -214,3 +214,29 @@ def test_mae_against_shimmed_reference_fixture(dev, golden_dir):
             assert rel < GRAD_RELL2_TOL, (k, rel)
         if k.startswith("gn."):
             assert params[k[3:]].grad is not None, k
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_recorder_attention_maps(dev, robust):
+    """Recorder(vit)(img) -> (preds, attns [B, depth, heads, N, N]) as in the reference's recorder.py; the maps are the
+    (Sinkhorn-normalised for robust=True) softmax of the layer's own q, k: rows sum to 1, and they reproduce the layer's
+    attention output when applied to v."""
+    from noise_robust_vit_amd import SimpleViT
+    from noise_robust_vit_amd import encoder
+    from noise_robust_vit_amd.recorder import Recorder
+    torch.manual_seed(0)
+    vit = SimpleViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, robust=robust).to(dev).eval()
+    x = torch.randn(3, 3, 64, 64, device=dev)
+    rec = Recorder(vit)
+    with torch.no_grad():
+        preds, attns = rec(x)
+        plain = vit(x)
+    assert torch.equal(preds, plain)
+    assert attns.shape == (3, 2, 2, 16, 16) and attns.dtype == torch.float32
+    assert (attns.sum(-1) - 1).abs().max().item() < 1e-3
+    if robust:
+        assert (attns.sum(-2) - 1).abs().max().item() < 5e-2          # columns are close to 1 after 3 Sinkhorn rounds
+    assert rec.eject() is vit
+    with pytest.raises(AssertionError):
+        rec(x)
+    assert encoder._RECORDING is None
