@@ -27,6 +27,15 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(const void* __restric
         const int b = (int)(t / (hh * ww));
         const int rem = (int)(t - (long long)b * hh * ww);
         const int py = rem / ww, px = rem - py * ww;
+        if (LAYOUT == NRV_PATCH_CP1P2 && !IMG_F32 && (p & 7) == 0 && (W & 7) == 0) {
+            // (c, p1, p2) order with p % 8 == 0: the 8 features are 8 consecutive pixels of one image row: one 16-byte copy
+            const int c = f0 / (p * p);
+            const int pp = f0 - c * p * p;
+            const int p1 = pp / p, p2 = pp - p1 * p;
+            const long long src = (((long long)b * C + c) * H + (py * p + p1)) * W + px * p + p2;
+            *reinterpret_cast<u32x4_t*>(out + t * F + f0) = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(img) + src);
+            continue;
+        }
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
