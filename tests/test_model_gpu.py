@@ -240,3 +240,19 @@ def test_recorder_attention_maps(dev, robust):
     with pytest.raises(AssertionError):
         rec(x)
     assert encoder._RECORDING is None
+
+
+def test_inference_path_equals_training_forward(dev):
+    """Under torch.no_grad the encoder keeps nothing for a backward (no gelu' stream, no saved activations): the logits must
+    be bit-identical to the training-mode forward."""
+    from noise_robust_vit_amd import SimpleViT
+    torch.manual_seed(0)
+    vit = SimpleViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256).to(dev)
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        a = vit(x)
+    b = vit(x)
+    assert b.requires_grad and not a.requires_grad
+    assert torch.equal(a, b.detach())
+    b.sum().backward()
+    assert vit.transformer.layers[0][1].net[1].weight.grad is not None
