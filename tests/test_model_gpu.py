@@ -256,3 +256,25 @@ def test_inference_path_equals_training_forward(dev):
     assert torch.equal(a, b.detach())
     b.sum().backward()
     assert vit.transformer.layers[0][1].net[1].weight.grad is not None
+
+
+def test_training_actually_learns(dev):
+    """End-to-end: Trainer (HIP forward / backward, fused clip + AdamW, batched weight re-staging) overfits one fixed batch.
+    Guards the whole loop -- e.g. the bf16 weight images going stale after an optimizer step, which no single-step parity
+    test can see."""
+    from noise_robust_vit_amd import SimpleViT
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    torch.manual_seed(0)
+    vit = SimpleViT(image_size=32, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256).to(dev).train()
+    tr = Trainer(vit, TrainConfig(lr=2e-3, weight_decay=0.05, grad_max_norm=5.0, label_smoothing=0.0))
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(32, 3, 32, 32, generator=g).to(dev)
+    y = torch.randint(0, 10, (32,), generator=g).to(dev)
+    first = tr.step(x, y).item()
+    for _ in range(60):
+        last = tr.step(x, y).item()
+    assert first > 2.0 and last < 0.25 * first, (first, last)
+    vit.eval()
+    with torch.no_grad():
+        acc = (vit(x).argmax(-1) == y).float().mean().item()
+    assert acc > 0.9, acc
