@@ -123,13 +123,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
     const bool col_ok = ncol < e.N;                     // N % 8 == 0: a chunk is entirely inside or outside
     constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
     constexpr bool AUX32 = EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32;
-    // Epilogue operands (residual stream / saved gelu') do not depend on the LDS transposition.  They are fetched in batches
-    // of BS 16-row slabs, TWO batches deep: while batch k is transposed / combined / stored, the loads of batch k+1 are in
-    // flight (one dependent load per slab made this phase latency-bound: 27 us per 256x256 fp32-residual tile; one batch at a
-    // time still exposes a memory round trip per batch).
-    constexpr int BS = MI > 8 ? 2 : (MI + 3) / 4;        // 2 x BS slabs of operands live at a time
-    constexpr int HALF = BS;
-    constexpr int NB = (MI + BS - 1) / BS;
+    constexpr int HALF = MI > 8 ? (MI + 3) / 4 : (MI + 1) / 2;      // operand-prefetch depth, bounded by the register file
 
     f32x4_t bias4[V];
 #pragma unroll
@@ -141,39 +135,36 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
         }
     }
 
-    f32x4_t aux32b[2][AUX32 ? BS : 1][NIT][V];
-    u32x2_t aux16b[2][(HAS_AUX && !AUX32) ? BS : 1][NIT][V];
-    auto fetch = [&](int bi, int slot) {
-        if (!HAS_AUX) return;
 #pragma unroll
-        for (int mh = 0; mh < BS; ++mh) {
-            const int mi = bi * BS + mh;
+    for (int h0 = 0; h0 < MI; h0 += HALF) {
+        // Epilogue operands (residual stream / saved pre-activation) do not depend on the LDS transposition:
+        // issue the loads of half the wave's block up front so that many requests per lane are in flight
+        // (one dependent load per slab made this phase latency-bound: 27 us per 256x256 fp32-residual tile).
+        f32x4_t aux32[AUX32 ? HALF : 1][NIT][V];
+        u32x2_t aux16[(HAS_AUX && !AUX32) ? HALF : 1][NIT][V];
+        if (HAS_AUX) {
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int m = row_base + mi * 16 + rrow + RPI * i;
-                const bool ok = mi < MI && m < e.M && col_ok;
-                const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
-                const long long arow = (EPI == NRV_EPI_BIAS_RESIDUAL && e.aux_row_mod > 0) ? (long long)(m % e.aux_row_mod) : orow;
+            for (int mh = 0; mh < HALF; ++mh) {
+                const int mi = h0 + mh;
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    if (AUX32) {
-                        aux32b[slot][mh][i][v] = ok ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.aux) + arow * e.ld_aux + ncol + 4 * v)
-                                                    : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    } else {
-                        aux16b[slot][mh][i][v] = ok ? *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + arow * e.ld_aux + ncol + 4 * v)
-                                                    : u32x2_t{0u, 0u};
+                for (int i = 0; i < NIT; ++i) {
+                    const int m = row_base + mi * 16 + rrow + RPI * i;
+                    const bool ok = mi < MI && m < e.M && col_ok;
+                    const long long orow = remap_row(m, e.out_group, e.out_group_stride, e.out_row_offset);
+                    const long long arow = (EPI == NRV_EPI_BIAS_RESIDUAL && e.aux_row_mod > 0) ? (long long)(m % e.aux_row_mod) : orow;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        if (AUX32) {
+                            aux32[mh][i][v] = ok ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.aux) + arow * e.ld_aux + ncol + 4 * v)
+                                                 : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            aux16[mh][i][v] = ok ? *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(e.aux) + arow * e.ld_aux + ncol + 4 * v)
+                                                 : u32x2_t{0u, 0u};
+                        }
                     }
                 }
             }
         }
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int bi = 0; bi < NB; ++bi) {
-        const int h0 = bi * BS;
-        if (bi + 1 < NB) fetch(bi + 1, (bi + 1) & 1);
-        auto& aux32 = aux32b[bi & 1];
-        auto& aux16 = aux16b[bi & 1];
 #pragma unroll
         for (int mh = 0; mh < HALF; ++mh) {
             const int mi = h0 + mh;
