@@ -119,7 +119,9 @@ def test_standalone_attention_and_feedforward_modules(dev):
 
 
 @pytest.mark.parametrize("cfg", [dict(image_size=32, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10),
-                                 dict(image_size=64, patch_size=16, num_layers=1, num_heads=2, hidden_dim=128, mlp_dim=256, num_classes=7)])
+                                 dict(image_size=64, patch_size=16, num_layers=1, num_heads=2, hidden_dim=128, mlp_dim=256, num_classes=7),
+                                 # ViT-L/16 geometry (BASELINE.json configs[3]): 16 heads, D 1024, M 4096, 197 tokens; 2 of its 24 layers
+                                 dict(image_size=224, patch_size=16, num_layers=2, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=11)])
 def test_vision_transformer_against_oracle(dev, cfg):
     """torchvision-style VisionTransformer (class token, learned positions, biased in/out projections, final LN).
     Parity unpinned by the reference (its forward cannot run): the oracle is pinned against
@@ -136,7 +138,7 @@ def test_vision_transformer_against_oracle(dev, cfg):
     model = VisionTransformer(**cfg)
     model.load_state_dict(sd)
     model = model.to(dev).train()
-    B = 5
+    B = 5 if cfg["hidden_dim"] < 1024 else 2
     x = torch.randn(B, 3, cfg["image_size"], cfg["image_size"], generator=g)
     y = torch.randint(0, cfg["num_classes"], (B,), generator=g)
     logits = model(x.to(dev))
@@ -149,8 +151,11 @@ def test_vision_transformer_against_oracle(dev, cfg):
     emu = V.vit_forward(sd, x, patch_size=cfg["patch_size"], num_heads=cfg["num_heads"], emulate_bf16=True)
     e_ref, e_emu = relmax(logits, ref), relmax(logits, emu)
     print(f"VT {cfg['hidden_dim']}: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}")
-    # class-token read-out (no mean pooling to average rounding-boundary flips): 3e-3 against the emulation
-    assert e_ref < LOGIT_TOL_FP32REF and e_emu < 3 * LOGIT_TOL_EMULATED
+    # class-token read-out (no mean pooling to average rounding-boundary flips): 3e-3 against the emulation for the small
+    # geometries; at 197 tokens x 2 layers the flips alone give 2e-3 .. 5e-3 (measured over five geometries: the kernels are
+    # always closer to the emulating oracle than the emulating oracle is to the fp32 one), hence 8e-3 for the ViT-L case
+    emu_tol = 3 * LOGIT_TOL_EMULATED if cfg["image_size"] < 224 else 8e-3
+    assert e_ref < LOGIT_TOL_FP32REF and e_emu < emu_tol
     assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
     ref_grads = {k: v.grad for k, v in leaves.items()}
     print("worst grad:", check_grads(model, ref_grads))
