@@ -185,3 +185,22 @@ def test_cutmix_box_and_trainer_loss_mix():
     out = net(xm)
     ce = lambda t: torch.nn.functional.cross_entropy(out, t, label_smoothing=0.1)
     assert abs(loss.item() - (ce(y) * lam + ce(y[perm]) * (1 - lam)).item()) < 1e-6
+
+
+def test_trainer_on_cpu_uses_torch_adamw_and_fused_optimizer_refuses_cpu():
+    """The fused optimizer is a HIP path: on CPU tensors the Trainer falls back to torch.optim.AdamW (whose arithmetic the
+    HIP kernels are pinned against on the GPU), and FusedAdamW itself refuses a CPU gradient buffer."""
+    from noise_robust_vit_amd._lib import NrvError
+    from noise_robust_vit_amd.optim import FusedAdamW
+    from noise_robust_vit_amd.parallel import GradReducer
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    net = torch.nn.Linear(4, 3)
+    tr = Trainer(net, TrainConfig(grad_max_norm=1.0))
+    assert isinstance(tr.opt, torch.optim.AdamW) and not tr.fused
+    w0 = net.weight.detach().clone()
+    tr.step(torch.randn(5, 4), torch.randint(0, 3, (5,)))
+    assert not torch.equal(w0, net.weight.detach())
+    red = GradReducer(torch.nn.Linear(4, 3), 1)
+    assert red.parameters() and red.slot(red.parameters()[0])[1] == 12
+    with pytest.raises(NrvError):
+        FusedAdamW(red, lr=1e-3)
