@@ -7,7 +7,7 @@ under ``noise_robust_vit_amd/``.  It exists so that parity tests can compare
 the HIP path against the reference's arithmetic on a box that does not hold
 the reference.
 
-Rules (enforced by ``tests/test_no_oracle_in_product.py``):
+Rules (enforced by ``tests/test_host_logic.py::test_product_never_imports_the_oracle_or_reads_the_reference``):
   * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
     ``cpu_baseline`` leg may import anything from here;
   * nothing under ``noise_robust_vit_amd/`` imports it, and the product path
