@@ -234,6 +234,13 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_ke
 //   dkv kernel: images Q, dO (+ lse, delta); wave owns 32 keys, sweeps the queries -> dK, dV
 // P is recomputed from the saved log-sum-exp; dS is scaled once at the end (dQ, dK are linear in it).
 // ---------------------------------------------------------------------------------------------
+// Backward images are read BOTH as rows (ds_read_b128, lane = row) and transposed (ds_read_b64_tr_b16): they use the 32-byte
+// PAIR swizzle of the forward V image (vimg_off), which is conflict-free for both patterns.  With the row-only swizzle
+// (img_off) the transposed reads were 2-way conflicted: SQ_LDS_BANK_CONFLICT = 24-29 % of SQ_LDS_IDX_ACTIVE in the PMC pass.
+__device__ __forceinline__ bf16x8_t row_frag_bwd(const char* img, int rb, int ks, int lane) {
+    return lds_read_b128(img + vimg_off(rb + (lane & 15), ks * 4 + (lane >> 4)));
+}
+
 // a 16 x 64 fp32 tile held as acc[dt][e] (lane (r = lane & 15, g = lane >> 4): row r, features 16 dt + 4 g + e) -> bf16,
 // regrouped with v_permlane16_swap so that a lane owns 8 consecutive features: two 16-byte stores per row
 __device__ __forceinline__ void store_tile_bf16(bf16_t* row_ptr /* row of this lane, feature 0 */, const f32x4_t (&acc)[4],
@@ -248,7 +255,7 @@ __device__ __forceinline__ void store_tile_bf16(bf16_t* row_ptr /* row of this l
     }
 }
 
-// DMA of two [N x 64] head slices into two GEMM-swizzled row images of NT * 16 rows (rows >= N: zero)
+// DMA of two [N x 64] head slices into two pair-swizzled row images of NT * 16 rows (rows >= N: zero)
 template <int NT>
 __device__ __forceinline__ void dma_two_images(char* smem, const bf16_t* src0, long long ld0, const bf16_t* src1, long long ld1,
                                                int N, int wave, int lane) {
@@ -260,7 +267,8 @@ __device__ __forceinline__ void dma_two_images(char* smem, const bf16_t* src0, l
         const int j = wave_u * NT + i;
         const bool second = j >= NP / 8;
         const int r = 8 * (second ? j - NP / 8 : j) + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int pos = lane & 7;
+        const int c = (((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1);      // source chunk that lands at position pos (pair swizzle)
         const unsigned vo = (r < N) ? (unsigned)(r * (second ? ld1 : ld0) * 2 + c * 16) : NRV_OOB;
         if (second) dma16(r1, smem + j * 1024, vo);
         else dma16(r0, smem + j * 1024, vo);
@@ -333,8 +341,8 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat
                     bf16x8_t kr[2], vr[2];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        kr[ks] = row_frag_img(kimg, kt * 16, ks, lane);
-                        vr[ks] = row_frag_img(vimg, kt * 16, ks, lane);
+                        kr[ks] = row_frag_bwd(kimg, kt * 16, ks, lane);
+                        vr[ks] = row_frag_bwd(vimg, kt * 16, ks, lane);
                     }
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -365,8 +373,8 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat
                 const int q4 = (lane & 15) >> 2, pp = lane & 3;
                 const int r0 = kk * 32 + 4 * g + q4;
                 const int c = 2 * dt + (pp >> 1);
-                const bf16x4_t lo = lds_read_tr16_b64(kimg + img_off(r0, c) + (pp & 1) * 8);
-                const bf16x4_t hi = (!LAST || NT % 2 == 0) ? lds_read_tr16_b64(kimg + img_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
+                const bf16x4_t lo = lds_read_tr16_b64(kimg + vimg_off(r0, c) + (pp & 1) * 8);
+                const bf16x4_t hi = (!LAST || NT % 2 == 0) ? lds_read_tr16_b64(kimg + vimg_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
                 const bf16x8_t ktr = cat4(lo, hi);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) dq[t][dt] = mfma16(ktr, dsf[t], dq[t][dt]);
@@ -441,8 +449,8 @@ __global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const 
         const int q4 = (lane & 15) >> 2, pp = lane & 3;
         const int r0 = qq * 32 + 4 * g + q4;
         const int c = 2 * dt + (pp >> 1);
-        const bf16x4_t lo = lds_read_tr16_b64(img + img_off(r0, c) + (pp & 1) * 8);
-        const bf16x4_t hi = (!decltype(last_c)::value || NT % 2 == 0) ? lds_read_tr16_b64(img + img_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
+        const bf16x4_t lo = lds_read_tr16_b64(img + vimg_off(r0, c) + (pp & 1) * 8);
+        const bf16x4_t hi = (!decltype(last_c)::value || NT % 2 == 0) ? lds_read_tr16_b64(img + vimg_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
         return cat4(lo, hi);
     };
     for (int pair = wave; pair < npairs; pair += ATF_WAVES) {
@@ -464,8 +472,8 @@ __global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const 
                     bf16x8_t qr[2], dor[2];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        qr[ks] = row_frag_img(qimg, qt * 16, ks, lane);
-                        dor[ks] = row_frag_img(doimg, qt * 16, ks, lane);
+                        qr[ks] = row_frag_bwd(qimg, qt * 16, ks, lane);
+                        dor[ks] = row_frag_bwd(doimg, qt * 16, ks, lane);
                     }
                     const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qt * 16 + 4 * g);
                     const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qt * 16 + 4 * g);
@@ -577,7 +585,8 @@ __global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(cons
             const int j = wave_u * NT + i;
             const int im = j / (NP / 8);                // 0 q, 1 k, 2 v, 3 dO
             const int r = 8 * (j - im * (NP / 8)) + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const int pos = lane & 7;
+            const int c = (((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1);
             const unsigned vo = (r < N) ? (unsigned)(r * (im == 3 ? ldo : ldq) * 2 + c * 16 + (im == 3 ? 0 : im) * H * DH * 2) : NRV_OOB;
             if (im == 3) dma16(rd, smem + j * 1024, vo);      // (a select between descriptors may end up in VGPRs)
             else dma16(rq, smem + j * 1024, vo);
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(cons
             float d = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t dof = row_frag_img(doimg, wave * 32 + t * 16, ks, lane);
+                const bf16x8_t dof = row_frag_bwd(doimg, wave * 32 + t * 16, ks, lane);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d += bf16_to_f32((unsigned short)dof[e]) * bf16_to_f32((unsigned short)of[t][ks][e]);
             }
@@ -612,8 +621,8 @@ __global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(cons
         const int q4 = (lane & 15) >> 2, pp = lane & 3;
         const int r0 = s32 * 32 + 4 * g + q4;
         const int c = 2 * dt + (pp >> 1);
-        const bf16x4_t lo = lds_read_tr16_b64(img + img_off(r0, c) + (pp & 1) * 8);
-        const bf16x4_t hi = (!decltype(last_c)::value || NT % 2 == 0) ? lds_read_tr16_b64(img + img_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
+        const bf16x4_t lo = lds_read_tr16_b64(img + vimg_off(r0, c) + (pp & 1) * 8);
+        const bf16x4_t hi = (!decltype(last_c)::value || NT % 2 == 0) ? lds_read_tr16_b64(img + vimg_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
         return cat4(lo, hi);
     };
 
@@ -626,8 +635,8 @@ __global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(cons
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    qf[t][ks] = row_frag_img(qimg, pair * 32 + t * 16, ks, lane);
-                    dof[t][ks] = row_frag_img(doimg, pair * 32 + t * 16, ks, lane);
+                    qf[t][ks] = row_frag_bwd(qimg, pair * 32 + t * 16, ks, lane);
+                    dof[t][ks] = row_frag_bwd(doimg, pair * 32 + t * 16, ks, lane);
                 }
                 dl[t] = dels[pair * 32 + t * 16 + rc];
                 lse2[t] = lse2s[pair * 32 + t * 16 + rc];
@@ -647,8 +656,8 @@ __global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(cons
                         bf16x8_t kr[2], vr[2];
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
-                            kr[ks] = row_frag_img(kimg, kt * 16, ks, lane);
-                            vr[ks] = row_frag_img(vimg, kt * 16, ks, lane);
+                            kr[ks] = row_frag_bwd(kimg, kt * 16, ks, lane);
+                            vr[ks] = row_frag_bwd(vimg, kt * 16, ks, lane);
                         }
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
@@ -697,8 +706,8 @@ __global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(cons
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    kf[t][ks] = row_frag_img(kimg, pair * 32 + t * 16, ks, lane);
-                    vf[t][ks] = row_frag_img(vimg, pair * 32 + t * 16, ks, lane);
+                    kf[t][ks] = row_frag_bwd(kimg, pair * 32 + t * 16, ks, lane);
+                    vf[t][ks] = row_frag_bwd(vimg, pair * 32 + t * 16, ks, lane);
                 }
             f32x4_t dk[2][4], dv[2][4];
 #pragma unroll
@@ -718,8 +727,8 @@ __global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(cons
                         bf16x8_t qr[2], dor[2];
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
-                            qr[ks] = row_frag_img(qimg, qt * 16, ks, lane);
-                            dor[ks] = row_frag_img(doimg, qt * 16, ks, lane);
+                            qr[ks] = row_frag_bwd(qimg, qt * 16, ks, lane);
+                            dor[ks] = row_frag_bwd(doimg, qt * 16, ks, lane);
                         }
                         const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qt * 16 + 4 * g);
                         const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qt * 16 + 4 * g);
