@@ -197,18 +197,12 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        # instrumented steps: HIP events around every C-ABI launch on the compute stream.  The dW / dX two-stream
-        # overlap is switched off here so that each kernel's duration is its own (overlapped kernels share the chip
-        # and their event spans would double-count); the timed region above runs with the overlap on.
-        from noise_robust_vit_amd import encoder as _enc
-        _overlap_was = _enc.OVERLAP_DW
-        _enc.set_overlap(False)
+        # instrumented steps: HIP events around every C-ABI launch on the compute stream
         with K.LaunchProfile() as prof:
             for _ in range(2):
                 if world == 1:
                     trainer.forward_backward(x, y)      # gradients are overwritten in the flat buffer every step
         summ = prof.summary() if world == 1 else {}
-        _enc.set_overlap(_overlap_was)
         if "gemm_nt" in summ:
             gnt = summ["gemm_nt"]
             ach = gnt["flops"] / (gnt["ms"] * 1e-3) / 1e12

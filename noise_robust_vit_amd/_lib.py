@@ -12,9 +12,8 @@ import threading
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, c_double
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NRV_LIB_PATH: developer override used to A/B kernel variants (tools/); the shipped path is the in-tree library
 _DEFAULT_LIB = os.path.join(_HERE, "lib", "libnrv_hip.so")
-LIB_PATH = os.environ.get("NRV_LIB_PATH") or _DEFAULT_LIB
+LIB_PATH = _DEFAULT_LIB       # no environment override: what runs is the in-tree library (tools/_devlib.py swaps it for A/B runs)
 
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
@@ -78,7 +77,7 @@ def load() -> ctypes.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH) and LIB_PATH == _DEFAULT_LIB and not os.environ.get("NRV_NO_AUTOBUILD"):
+        if not os.path.exists(LIB_PATH) and LIB_PATH == _DEFAULT_LIB:
             # the in-tree library is a build product (git-ignored): compile it if the toolchain is here.  This is
             # the same HIP code path, not a fallback; without hipcc the error below is raised.
             try:
@@ -91,16 +90,21 @@ def load() -> ctypes.CDLL:
             raise NrvError(
                 f"{LIB_PATH} not found: the HIP kernels are the product and there is no fallback path. "
                 "Build them with `python -m noise_robust_vit_amd.build` (needs hipcc, gfx950 target).")
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)          # AttributeError if the library does not export it
-            fn.restype = res
-            fn.argtypes = args
-        got = lib.nrv_abi_version()
-        if got != ABI_VERSION:
-            raise NrvError(f"libnrv_hip.so ABI version {got} != binding version {ABI_VERSION}; rebuild the library")
-        _lib = lib
+        _lib = bind(LIB_PATH)
     return _lib
+
+
+def bind(path: str) -> ctypes.CDLL:
+    """dlopen `path` and set the prototype of every symbol include/nrv.h declares."""
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.nrv_abi_version()
+    if got != ABI_VERSION:
+        raise NrvError(f"{path}: ABI version {got} != binding version {ABI_VERSION}; rebuild the library")
+    return lib
 
 
 def check(code: int, what: str) -> None:

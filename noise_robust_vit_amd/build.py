@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnrv_hip.so")
-SOURCES = ["nrv_gemm.hip", "nrv_gemm_persist.hip", "nrv_norm.hip", "nrv_attn.hip", "nrv_misc.hip", "nrv_sinkhorn.hip", "nrv_optim.hip"]
+SOURCES = ["nrv_gemm.hip", "nrv_norm.hip", "nrv_attn.hip", "nrv_misc.hip", "nrv_sinkhorn.hip", "nrv_optim.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wall", "-Wno-unused-function"]
@@ -45,31 +45,35 @@ def _stale(target: str, srcs: list) -> bool:
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src: str, force: bool, objdir: str = OBJ, extra: tuple = ()) -> str:
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if force or _stale(obj, [path] + _deps()):
-        cmd = [_hipcc()] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [_hipcc()] + FLAGS + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
-    os.makedirs(LIBDIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, lib: str = LIB, objdir: str = OBJ, extra_flags: tuple = ()) -> str:
+    """The product library by default.  `lib` / `objdir` / `extra_flags` exist for tools/build_dev.py, which compiles
+    instrumented or experimental variants of the same sources into tools/_build/ (never loaded by the package)."""
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    with cf.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if len(srcs) != len(SOURCES):
+        raise RuntimeError(f"missing HIP sources: {sorted(set(SOURCES) - set(srcs))}")
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, objdir, extra_flags), srcs))
+    if force or _stale(lib, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"built {LIB} ({os.path.getsize(LIB)} bytes)")
-    return LIB
+        print(f"built {lib} ({os.path.getsize(lib)} bytes)")
+    return lib
 
 
 if __name__ == "__main__":

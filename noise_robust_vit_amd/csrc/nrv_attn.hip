@@ -20,8 +20,6 @@
 //   dq kernel : wave owns 32 queries, sweeps keys    -> dQ, and delta = rowsum(dO * O)
 //   dkv kernel: wave owns 32 keys,    sweeps queries -> dK, dV
 // P is recomputed from q, k and the saved log-sum-exp.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "nrv_attn_common.hpp"
@@ -532,260 +530,6 @@ __global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// backward, fused fat waves: ONE workgroup of 8 waves (2 per SIMD, <= 256 VGPRs) per (batch, head) holds the four
-// images Q, K, V, dO in LDS (4 x NT x 2 KiB), loaded once by LDS-DMA: 200 KB of HBM traffic per head instead of the
-// 300 KB of the two-kernel form (which reads q, k, v, dO twice).  After a short prologue (delta = rowsum(dO * O) for
-// 32 rows per wave -> LDS) the waves split by ROLE: waves 0-3 own query tiles (dQ), waves 4-7 own key tiles (dK, dV);
-// the two waves of a SIMD (w and w + 4) therefore run different phases of different work, and all row fragments of
-// the owned tiles come from the images (no second trip to HBM).
-// ---------------------------------------------------------------------------------------------
-constexpr int ATB_THREADS = 512;
-
-template <int NT>
-__global__ __launch_bounds__(ATB_THREADS, 2) void attn_bwd_fused_fat_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NP = NT * 16;
-    constexpr int NS = (NT + 1) / 2;
-    constexpr int NPS = NS * 32;
-    constexpr int IMG = NP * 128;
-    const char* qimg = smem;
-    const char* kimg = smem + IMG;
-    const char* vimg = smem + 2 * IMG;
-    const char* doimg = smem + 3 * IMG;
-    float* lse2s = reinterpret_cast<float*>(smem + 4 * IMG);
-    float* dels = lse2s + NPS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = p.N, H = p.H;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const long long ldq = 3ll * H * DH, ldo = (long long)H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    const bf16_t* obase = p.out + (long long)b * N * ldo + h * DH;
-    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
-    const int g = lane >> 4, rc = lane & 15;
-    const float sc = p.scale * LOG2E;
-    const int npairs = (N + 31) >> 5;
-
-    // ---- prologue: O rows of this wave's 32 queries (registers), then the four images
-    bf16x8_t of[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int q = wave * 32 + t * 16 + rc;
-        const int qr = q < N ? q : N - 1;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) of[t][ks] = load_frag_global(obase + (long long)qr * ldo + ks * 32 + g * 8);
-    }
-    for (int i = tid; i < NPS; i += ATB_THREADS)
-        lse2s[i] = i < N ? p.lse[((long long)b * H + h) * N + i] * LOG2E : INFINITY;      // exp2(s - inf) = 0 for padded queries
-    {
-        const __amdgpu_buffer_rsrc_t rq = make_rsrc(qbase, 0x7fffffffull), rd = make_rsrc(dobase, 0x7fffffffull);
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {                  // 4 images x NP / 8 = 8 NT instructions, NT per wave
-            const int j = wave_u * NT + i;
-            const int im = j / (NP / 8);                // 0 q, 1 k, 2 v, 3 dO
-            const int r = 8 * (j - im * (NP / 8)) + (lane >> 3);
-            const int pos = lane & 7;
-            const int c = (((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1);
-            const unsigned vo = (r < N) ? (unsigned)(r * (im == 3 ? ldo : ldq) * 2 + c * 16 + (im == 3 ? 0 : im) * H * DH * 2) : NRV_OOB;
-            if (im == 3) dma16(rd, smem + j * 1024, vo);      // (a select between descriptors may end up in VGPRs)
-            else dma16(rq, smem + j * 1024, vo);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" ::: "memory");
-    __syncthreads();
-    // delta of 32 rows per wave (8 x 32 = 256 >= NPS rows)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int q = wave * 32 + t * 16 + rc;
-        if (wave * 32 + t * 16 < NP) {
-            float d = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t dof = row_frag_bwd(doimg, wave * 32 + t * 16, ks, lane);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += bf16_to_f32((unsigned short)dof[e]) * bf16_to_f32((unsigned short)of[t][ks][e]);
-            }
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
-            if (g == 0) dels[q] = q < N ? d : 0.f;
-        } else if (wave * 32 + t * 16 < NPS) {
-            if (g == 0) dels[q] = 0.f;
-        }
-    }
-    __syncthreads();
-
-    const bf16x4_t zero4 = {0, 0, 0, 0};
-    auto tr_frag = [&](const char* img, int s32, int dt, auto last_c) {     // rows s32*32 .. +31 transposed, features 16 dt ..
-        const int q4 = (lane & 15) >> 2, pp = lane & 3;
-        const int r0 = s32 * 32 + 4 * g + q4;
-        const int c = 2 * dt + (pp >> 1);
-        const bf16x4_t lo = lds_read_tr16_b64(img + vimg_off(r0, c) + (pp & 1) * 8);
-        const bf16x4_t hi = (!decltype(last_c)::value || NT % 2 == 0) ? lds_read_tr16_b64(img + vimg_off(r0 + 16, c) + (pp & 1) * 8) : zero4;
-        return cat4(lo, hi);
-    };
-
-    if (wave < 4) {
-        // ================= role: query owner -> dQ
-        for (int pair = wave; pair < npairs; pair += 4) {
-            bf16x8_t qf[2][2], dof[2][2];
-            float dl[2], lse2[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    qf[t][ks] = row_frag_bwd(qimg, pair * 32 + t * 16, ks, lane);
-                    dof[t][ks] = row_frag_bwd(doimg, pair * 32 + t * 16, ks, lane);
-                }
-                dl[t] = dels[pair * 32 + t * 16 + rc];
-                lse2[t] = lse2s[pair * 32 + t * 16 + rc];
-            }
-            f32x4_t dq[2][4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dq[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            auto step = [&](const int kk, auto last_c) {
-                constexpr bool LAST = decltype(last_c)::value;
-                f32x4_t ds[2][2];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int kt = 2 * kk + hf;
-                    if (!LAST || hf == 0 || (NT % 2 == 0)) {
-                        bf16x8_t kr[2], vr[2];
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            kr[ks] = row_frag_bwd(kimg, kt * 16, ks, lane);
-                            vr[ks] = row_frag_bwd(vimg, kt * 16, ks, lane);
-                        }
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int ks = 0; ks < 2; ++ks) {
-                                st = mfma16(kr[ks], qf[t][ks], st);
-                                dp = mfma16(vr[ks], dof[t][ks], dp);
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -lse2[t]));
-                                if (LAST) pv = (kt * 16 + 4 * g + e < N) ? pv : 0.f;
-                                ds[t][hf][e] = pv * (dp[e] - dl[t]);
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) ds[t][hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-                bf16x8_t dsf[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) dsf[t] = pack_frag(ds[t][0], ds[t][1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8_t ktr = tr_frag(kimg, kk, dt, last_c);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) dq[t][dt] = mfma16(ktr, dsf[t], dq[t][dt]);
-                }
-            };
-#pragma unroll 1
-            for (int kk = 0; kk < NS - 1; ++kk) step(kk, std::false_type{});
-            step(NS - 1, std::true_type{});
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int q = pair * 32 + t * 16 + rc;
-                store_tile_bf16(p.dqkv + ((long long)b * N + (q < N ? q : 0)) * ldq + h * DH, dq[t], p.scale, g, q < N);
-            }
-        }
-    } else {
-        // ================= role: key owner -> dK, dV
-        for (int pair = wave - 4; pair < npairs; pair += 4) {
-            bf16x8_t kf[2][2], vf[2][2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    kf[t][ks] = row_frag_bwd(kimg, pair * 32 + t * 16, ks, lane);
-                    vf[t][ks] = row_frag_bwd(vimg, pair * 32 + t * 16, ks, lane);
-                }
-            f32x4_t dk[2][4], dv[2][4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    dk[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    dv[t][dt] = dk[t][dt];
-                }
-            auto step = [&](const int qq, auto last_c) {
-                constexpr bool LAST = decltype(last_c)::value;
-                f32x4_t pt[2][2], ds[2][2];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int qt = 2 * qq + hf;
-                    if (!LAST || hf == 0 || (NT % 2 == 0)) {
-                        bf16x8_t qr[2], dor[2];
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            qr[ks] = row_frag_bwd(qimg, qt * 16, ks, lane);
-                            dor[ks] = row_frag_bwd(doimg, qt * 16, ks, lane);
-                        }
-                        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2s + qt * 16 + 4 * g);
-                        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dels + qt * 16 + 4 * g);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int ks = 0; ks < 2; ++ks) {
-                                st = mfma16(qr[ks], kf[t][ks], st);
-                                dp = mfma16(dor[ks], vf[t][ks], dp);
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -l4[e]));
-                                pt[t][hf][e] = pv;
-                                ds[t][hf][e] = pv * (dp[e] - d4[e]);
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            pt[t][hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                            ds[t][hf] = pt[t][hf];
-                        }
-                    }
-                }
-                bf16x8_t pf[2], dsf[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    pf[t] = pack_frag(pt[t][0], pt[t][1]);
-                    dsf[t] = pack_frag(ds[t][0], ds[t][1]);
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8_t dotr = tr_frag(doimg, qq, dt, last_c);
-                    const bf16x8_t qtr = tr_frag(qimg, qq, dt, last_c);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        dv[t][dt] = mfma16(dotr, pf[t], dv[t][dt]);
-                        dk[t][dt] = mfma16(qtr, dsf[t], dk[t][dt]);
-                    }
-                }
-            };
-#pragma unroll 1
-            for (int qq = 0; qq < NS - 1; ++qq) step(qq, std::false_type{});
-            step(NS - 1, std::true_type{});
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int key = pair * 32 + t * 16 + rc;
-                bf16_t* row = p.dqkv + ((long long)b * N + (key < N ? key : 0)) * ldq + h * DH;
-                store_tile_bf16(row + H * DH, dk[t], p.scale, g, key < N);
-                store_tile_bf16(row + 2 * H * DH, dv[t], 1.0f, g, key < N);
-            }
-        }
-    }
-}
-
 template <int NT>
 int launch_fwd_fat_nt(const AttnParams& p, hipStream_t s) {
     constexpr int lds = 2 * NT * 16 * 128;
@@ -828,33 +572,8 @@ int launch_bwd_fat_nt(const AttnParams& p, hipStream_t s) {
     return 0;
 }
 
-template <int NT>
-int launch_bwd_fused_fat_nt(const AttnParams& p, hipStream_t s) {
-    constexpr int lds = 4 * NT * 16 * 128 + 2 * ((NT + 1) / 2) * 32 * 4;
-    static int a1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_fat_kernel<NT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (a1 != 0) return a1;
-    hipLaunchKernelGGL((attn_bwd_fused_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATB_THREADS), lds, s, p);
-    NRV_CHECK_LAUNCH();
-    return 0;
-}
-
 int launch_bwd_fat(const AttnParams& p, hipStream_t s) {
     const int nt = (p.N + 15) / 16;
-    // single-kernel form (attn_bwd_fused_fat_kernel): 2/3 of the HBM traffic but one workgroup per CU, so a head's loads
-    // are not overlapped with another head's arithmetic: measured equal (0.245 vs 0.244 ms); opt-in until it prefetches
-    static const int fused = [] { const char* e = getenv("NRV_ATTN_BWD_FUSED"); return e ? atoi(e) : 0; }();
-    if (fused) {
-        if (nt <= 2) return launch_bwd_fused_fat_nt<2>(p, s);
-        if (nt <= 4) return launch_bwd_fused_fat_nt<4>(p, s);
-        if (nt <= 6) return launch_bwd_fused_fat_nt<6>(p, s);
-        if (nt <= 8) return launch_bwd_fused_fat_nt<8>(p, s);
-        if (nt <= 10) return launch_bwd_fused_fat_nt<10>(p, s);
-        if (nt <= 12) return launch_bwd_fused_fat_nt<12>(p, s);
-        if (nt == 13) return launch_bwd_fused_fat_nt<13>(p, s);
-        if (nt == 14) return launch_bwd_fused_fat_nt<14>(p, s);
-        return launch_bwd_fused_fat_nt<16>(p, s);
-    }
     if (nt <= 2) return launch_bwd_fat_nt<2>(p, s);
     if (nt <= 4) return launch_bwd_fat_nt<4>(p, s);
     if (nt <= 6) return launch_bwd_fat_nt<6>(p, s);

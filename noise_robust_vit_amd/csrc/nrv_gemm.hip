@@ -18,7 +18,6 @@
 //     every global access of the epilogue is a full 16-byte, row-contiguous access.
 //
 // Reference call sites replaced: simple_vit.py:39,41,61,62,130 ; vit.py:40-47 ; utils.py:115,579.
-#include <stdlib.h>
 
 #include "nrv_common.hpp"
 
@@ -35,10 +34,11 @@ constexpr int B_TILE_OFF = 32768;
 constexpr int GEMM_LDS_BYTES = 2 * STAGE_BYTES;
 
 // NT tile configurations: WM x WN waves, each wave MI x NI MFMA tiles of 16x16 (NI is 4 everywhere: the
-// epilogue transposes 16 x 64 slabs).
-//   Cfg256: 256x256 tile, 8 waves, 128 KiB LDS, one workgroup per CU  -- least L2 traffic per FLOP
-//   Cfg192: 192x128 tile, 4 waves,  80 KiB LDS, TWO workgroups per CU -- one workgroup's epilogue / prologue
-//           overlaps the other's MFMA main loop; the tile granularity also halves wave-quantisation loss
+// epilogue transposes 16 x 64 slabs).  One workgroup per CU.
+//   Cfg256: 256x256 tile, 8 waves, 128 KiB LDS -- least L2 traffic per FLOP among the square tiles
+//   Cfg320: 320x256 tile: fewer rounds of workgroups on the N = 768 shapes (474 tiles = 2 rounds instead of 591 = 3)
+// (192x128 / 128x256 tiles with two workgroups per CU, a 4-slot ring variant and a persistent deferred-epilogue kernel
+// were measured slower in round 1 and are not part of the library any more: DESIGN.md "tried and rejected".)
 template <int WM_, int WN_, int MI_, int NI_>
 struct TileCfg {
     static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
@@ -51,9 +51,7 @@ struct TileCfg {
     static_assert(TBM * 8 % THREADS == 0 && TBN * 8 % THREADS == 0, "whole DMA instructions");
 };
 using Cfg256 = TileCfg<2, 4, 8, 4>;
-using Cfg192 = TileCfg<2, 2, 6, 4>;
-using Cfg128 = TileCfg<2, 4, 4, 4>;
-using Cfg320 = TileCfg<2, 4, 10, 4>;     // 320x256 tile: 474 tiles for [50432 x 768] = 2 rounds of 256 CUs (256x256: 591 = 3 rounds)      // 128x256 tile, 8 waves: finer tile granularity for N = 768 shapes
+using Cfg320 = TileCfg<2, 4, 10, 4>;
 constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
 constexpr int EPI_PATCH_BYTES = 16 * EPI_ROW_F32 * 4;   // 4352 B per wave
 
@@ -74,9 +72,10 @@ struct GemmNTParams {
     long long lda, ldb;
     int K;
     int tiles_n;
-    int stagger;
     int gn;                       // column-group width of the tile order (0 = plain row-major sweep)
-    unsigned long long* stamps;   // debug only (NRV_GEMM_STAMPS=1): 4 x s_memrealtime + hw id per workgroup
+#ifdef NRV_DEV_STAMPS
+    unsigned long long* stamps;   // tools/ build only: 4 x s_memrealtime + hw id per workgroup
+#endif
     EpiParams e;
 };
 
@@ -310,15 +309,19 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
         for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (K + BK - 1) / BK;
+#ifdef NRV_DEV_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (p.stamps) t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int d = 0; d < ND; ++d) dma_one(0, 0, d);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef NRV_DEV_STAMPS
         if (p.stamps && kt == 0) t1 = __builtin_amdgcn_s_memrealtime();
+#endif
         const bool more = kt + 1 < nk;
         const char* sa = smem + cur * C::STAGE;
         // The next tile's DMA instructions are spread over the MFMA groups of this tile (each costs the issuing
@@ -354,8 +357,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
         }
     }
     __syncthreads();     // every wave is done with the tile buffers: reuse them as epilogue patches
+#ifdef NRV_DEV_STAMPS
     if (p.stamps) t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     epilogue<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
+#ifdef NRV_DEV_STAMPS
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -365,137 +371,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
             o[4] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4 /* HW_REG_HW_ID */) | ((unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20 /* XCC_ID */) << 32);
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// NT kernel, deep-ring variant: same 256x256 tile and wave layout, but K is streamed in 32-deep HALF-steps through a
-// ring of FOUR 32 KiB LDS slots (16 KiB A + 16 KiB B), and the MFMA operands are double-buffered in REGISTERS:
-//     half-step s:   wait (counted) for slot s+1   |  barrier  |  DMA of half-step s+4 -> the slot half-step s just left
-//                    12 ds_read_b128 of half-step s+1 -> fragment set B, sprinkled between the
-//                    32 MFMAs of half-step s from fragment set A (read during half-step s-1)
-// so (1) a DMA has three half-steps (1.5 K-steps of MFMA time) to land instead of half a K-step -- the 2-stage kernel
-// above stalls on vmcnt(0) every K-step, it is LDS-DMA *latency* bound --, (2) the fragment reads of a
-// half-step are never waited for inside it, and (3) the barrier has MFMAs queued on both sides.
-// LDS image: [256 rows][32 k] bf16 = 64-byte rows; chunk c (0..3) of row r sits at position c ^ G[(r >> 2) & 3],
-// G = {0, 3, 2, 1}: conflict-free ds_read_b128 for the fragment pattern (4 rows share a 256-byte bank row).
-// vmcnt bookkeeping: 4 DMA instructions per wave per half-step, no other vector-memory instruction inside the loop.
-// ---------------------------------------------------------------------------------------------
-constexpr int R_BK = 32, R_NST = 4, R_STAGE = 32768, R_B_OFF = 16384, R_LDS = R_NST * R_STAGE;
-
-__device__ __forceinline__ int ring_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
-
-template <int EPI, bool OUT_F32, bool AUX_F32>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ring_kernel(const GemmNTParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    if (p.gn > 0 && p.tiles_n > p.gn) {
-        const int tiles_m = gridDim.x / p.tiles_n;
-        const int gsize = tiles_m * p.gn;
-        const int grp = id / gsize, within = id - grp * gsize;
-        const int gw = (grp + 1) * p.gn <= p.tiles_n ? p.gn : p.tiles_n - grp * p.gn;
-        tm = within / gw;
-        tn = grp * p.gn + (within - tm * gw);
-    } else {
-        tm = id / p.tiles_n;
-        tn = id - tm * p.tiles_n;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int M = p.e.M, N = p.e.N, K = p.K;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
-
-    // staging: DMA instruction i (0,1) of this wave fills rows 16*(8 i + wave) .. +15 of a half-step tile
-    unsigned st_a[2], st_b[2];
-    int st_k[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (i * 8 + wave) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ring_swz(r);
-        st_k[i] = c * 8;
-        st_a[i] = (m0 + r < M) ? (unsigned)((long long)r * p.lda * 2) + c * 16 : NRV_OOB;
-        st_b[i] = (n0 + r < N) ? (unsigned)((long long)r * p.ldb * 2) + c * 16 : NRV_OOB;
-    }
-    const int nk = (K + R_BK - 1) / R_BK;
-    // one of the 4 DMA instructions of half-step s (d = 0,1: A rows; 2,3: B rows)
-    auto dma_one = [&](int s, int d) {
-        char* base = smem + (s & (R_NST - 1)) * R_STAGE;
-        const int k0 = s * R_BK;
-        const int i = d & 1;
-        const bool kok = (k0 + st_k[i]) < K;
-        if (d < 2) dma16(ra, base + (i * 8 + wave) * 1024, (kok && st_a[i] != NRV_OOB) ? st_a[i] + k0 * 2 : NRV_OOB);
-        else dma16(rb, base + R_B_OFF + (i * 8 + wave) * 1024, (kok && st_b[i] != NRV_OOB) ? st_b[i] + k0 * 2 : NRV_OOB);
-    };
-
-    const int fr = lane & 15, fg = lane >> 4;
-    // row = 16 q + fr  ->  (row >> 2) & 3 = (fr >> 2) & 3 (16 q is a multiple of 16)
-    const int a_rd = (wr * 128 + fr) * 64 + ((fg ^ ring_swz(fr)) << 4);
-    const int b_rd = R_B_OFF + (wc * 64 + fr) * 64 + ((fg ^ ring_swz(fr)) << 4);
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // two fragment sets (A: 8 row tiles, B: 4 column tiles of one 32-deep half-step)
-    bf16x8_t fa0[8], fb0[4], fa1[8], fb1[4];
-    auto read_frags = [&](int s, bf16x8_t (&fa)[8], bf16x8_t (&fb)[4], int mi) {      // the reads that accompany row tile mi
-        const char* sa = smem + (s & (R_NST - 1)) * R_STAGE;
-        fa[mi] = lds_read_b128(sa + (a_rd + mi * 1024));
-        if (mi < 4) fb[mi] = lds_read_b128(sa + (b_rd + mi * 1024));
-    };
-
-    // prologue: half-steps 0..3 in flight, wait for 0, read its fragments
-#pragma unroll
-    for (int s = 0; s < R_NST; ++s)
-        if (s < nk) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) dma_one(s, d);
-        }
-    {
-        const int younger = (nk > 3 ? 12 : (nk > 2 ? 8 : (nk > 1 ? 4 : 0)));
-        switch (younger) {
-            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) read_frags(0, fa0, fb0, mi);
-    }
-
-    // one half-step: MFMAs of s from (fa, fb); fragments of s+1 into (na, nb); DMA of s+4
-    auto half_step = [&](int s, bf16x8_t (&fa)[8], bf16x8_t (&fb)[4], bf16x8_t (&na)[8], bf16x8_t (&nb)[4]) {
-        const bool has_next = s + 1 < nk;
-        // slot s+1 must have landed: younger DMA groups are those of s+2, s+3 (s+4 is issued below)
-        const int younger = (s + 3 < nk ? 8 : (s + 2 < nk ? 4 : 0));
-        if (younger == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (younger == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);                   // (guide rule 18: keep the MFMAs behind the wait)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const bool more = s + R_NST < nk;                    // slot s & 3 was read during half-step s-1: free now
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            if (has_next) read_frags(s + 1, na, nb, mi);
-            if (more && mi < 4) dma_one(s + R_NST, mi);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
-        }
-    };
-    for (int s = 0; s < nk; s += 2) {
-        half_step(s, fa0, fb0, fa1, fb1);
-        if (s + 1 < nk) half_step(s + 1, fa1, fb1, fa0, fb0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    epilogue<EPI, OUT_F32, AUX_F32, 8>(acc, smem, p.e, m0 + wr * 128, n0 + wc * 64, lane, wave);     // ring is idle: reuse it
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -667,17 +543,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long long 
     }
 }
 
-// debug: per-workgroup phase stamps (NRV_GEMM_STAMPS=1).  Never enabled in measured or shipped runs.
+#ifdef NRV_DEV_STAMPS
+// per-workgroup phase stamps: compiled only into the developer library (tools/build_dev.py), never into libnrv_hip.so
 constexpr size_t STAMP_BYTES = 8u << 20;
 unsigned long long* debug_stamp_buffer() {
     static unsigned long long* buf = [] {
-        const char* e = getenv("NRV_GEMM_STAMPS");
         void* p = nullptr;
-        if (e && atoi(e) && hipMalloc(&p, STAMP_BYTES) != hipSuccess) p = nullptr;
+        if (hipMalloc(&p, STAMP_BYTES) != hipSuccess) p = nullptr;
         return static_cast<unsigned long long*>(p);
     }();
     return buf;
 }
+#endif
 
 template <typename KernelT>
 int set_lds(KernelT k, int bytes) {
@@ -690,32 +567,16 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
     if (attr != 0) return attr;
     const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
     p.tiles_n = tiles_n;
-    static const int stagger = [] { const char* e = getenv("NRV_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-    p.stagger = stagger;
-    static const int gn = [] { const char* e = getenv("NRV_GEMM_GN"); return e ? atoi(e) : 4; }();     // measured: 8192^3 1111 -> 1336 TFLOP/s
-    p.gn = gn;
+    p.gn = 4;               // column groups of 4 tiles per XCD (swept 2, 3, 4, 6, 12, off in round 1: 8192^3 1111 -> 1336 TFLOP/s)
+#ifdef NRV_DEV_STAMPS
     p.stamps = debug_stamp_buffer();
+#endif
     hipLaunchKernelGGL((gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }
 
-template <int EPI, bool OUT_F32, bool AUX_F32>
-int launch_nt_ring(GemmNTParams p, hipStream_t s) {
-    static int attr = set_lds(gemm_nt_ring_kernel<EPI, OUT_F32, AUX_F32>, R_LDS);
-    if (attr != 0) return attr;
-    const int tiles_m = (int)nrv_cdiv(p.e.M, BM), tiles_n = (int)nrv_cdiv(p.e.N, BN);
-    p.tiles_n = tiles_n;
-    static const int gn = [] { const char* e = getenv("NRV_GEMM_GN"); return e ? atoi(e) : 4; }();
-    p.gn = gn;
-    p.stagger = 0;
-    p.stamps = nullptr;
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), R_LDS, s, p);
-    NRV_CHECK_LAUNCH();
-    return 0;
-}
-
-// tile selection: NRV_GEMM_TILE=256|192 forces a configuration (bench / tests); default = heuristic
+// tile selection
 int device_cus() {
     static int n = [] {
         int dev = 0, v = 256;
@@ -727,8 +588,6 @@ int device_cus() {
 }
 
 int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
-    static const int forced = [] { const char* e = getenv("NRV_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (forced == 256 || forced == 192 || forced == 128 || forced == 32 || forced == 320) return forced;
     (void)K;
     // One workgroup per CU: the kernel takes ceil(tiles / CUs) rounds of one tile time each.  Pick the tile height
     // with the smaller rounds x rows product; e.g. [50432 x 768]: 591 tiles of 256 rows = 3 rounds, 474 tiles of 320
@@ -744,11 +603,8 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
     const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
-    if (tc == 32) return launch_nt_ring<EPI, OUT_F32, AUX_F32>(p, s);
     if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32>(p, s);
-    if (tc == 256) return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
-    if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32>(p, s);
-    return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32>(p, s);
+    return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
 }
 
 int tn_splits(int64_t M, int64_t N, int64_t T) {
@@ -762,13 +618,6 @@ int tn_splits(int64_t M, int64_t N, int64_t T) {
 }
 
 }  // namespace
-
-// persistent kernel (nrv_gemm_persist.hip): returns -1000 when the shape is not for it
-int nrv_gemm_nt_persist_try(const void* A, long long lda, const void* B, long long ldb, void* C, int c_dtype, long long ldc,
-                            long long M, long long N, long long K, int epilogue_id, const float* bias,
-                            const void* aux, int aux_dtype, long long ld_aux, long long aux_row_mod,
-                            void* aux_out, long long ld_aux_out,
-                            long long out_group, long long out_group_stride, long long out_row_offset, hipStream_t s);
 
 extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
                                 void* C, int c_dtype, int64_t ldc,
@@ -799,15 +648,6 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     if (bias && !nrv_aligned16(bias)) return NRV_ERR_ALIGN;
     if (aux_out && (ld_aux_out < N || (ld_aux_out & 7) || !nrv_aligned16(aux_out))) return NRV_ERR_ALIGN;
 
-    // persistent kernel: correct (tests/test_kernels_gpu.py::test_gemm_nt_persistent_many_tiles) but measured slower than the
-    // one-tile-per-workgroup kernel on every ViT-B/16 shape: opt-in only
-    static const int persist = [] { const char* e = getenv("NRV_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
-    if (persist) {
-        const int r = nrv_gemm_nt_persist_try(A, lda, B, ldb, C, c_dtype, ldc, M, N, K, epilogue_id, bias, aux, aux_dtype, ld_aux,
-                                              aux_row_mod, aux_out, ld_aux_out, out_group, out_group_stride, out_row_offset,
-                                              static_cast<hipStream_t>(stream));
-        if (r != -1000) return r;
-    }
     GemmNTParams p;
     p.A = static_cast<const bf16_t*>(A);
     p.B = static_cast<const bf16_t*>(B);
@@ -838,11 +678,13 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     }
 }
 
-extern "C" int nrv_debug_read_stamps(unsigned long long* host_out, size_t count) {
+#ifdef NRV_DEV_STAMPS
+extern "C" int nrv_dev_read_stamps(unsigned long long* host_out, size_t count) {
     unsigned long long* b = debug_stamp_buffer();
     if (!b || !host_out || count * 8 > STAMP_BYTES) return NRV_ERR_NULL;
     return (int)hipMemcpy(host_out, b, count * 8, hipMemcpyDeviceToHost);
 }
+#endif
 
 extern "C" size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T) {
     if (M <= 0 || N <= 0 || T <= 0) return 0;

@@ -18,7 +18,6 @@ Nothing here computes with torch ops: torch supplies memory, streams and the aut
 """
 from __future__ import annotations
 
-import os
 import weakref
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
@@ -31,7 +30,6 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_NO
 Tensor = torch.Tensor
 
 PARAMS_PER_LAYER = 12   # ln1_w ln1_b wqkv bqkv wo bo ln2_w ln2_b w1 b1 w2 b2
-GRAD_STREAM_BF16 = os.environ.get("NRV_GRAD_STREAM", "fp32") == "bf16"
 
 
 # ----------------------------------------------------------------------------------------------
@@ -101,12 +99,6 @@ class BlockMeta:
     sink: Optional[object] = None
 
 
-def _require_softmax(meta: BlockMeta) -> None:
-    if meta.robust:
-        from .sinkhorn import require_available
-        require_available()
-
-
 def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
     """(out, beta) for a weight gradient: the sink's flat-buffer view if a sink is attached, else fresh."""
     if p is None:
@@ -114,35 +106,6 @@ def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
     if meta.sink is not None:
         return meta.sink.target(p)
     return None, 0.0
-
-
-# The weight-gradient GEMM (dW = dy^T x) and the input-gradient GEMM (dx = dy W) of one Linear only share their
-# input dy.  They are enqueued on two HIP streams so that the hardware dispatcher fills one kernel's partial last
-# round of tiles (591 tiles on 256 CUs = 2.3 rounds) with the other kernel's workgroups, and so that the two kernels'
-# epilogue bursts hit HBM out of phase.  NRV_OVERLAP_DW=0 puts everything back on one stream.
-OVERLAP_DW = os.environ.get("NRV_OVERLAP_DW", "0") != "0"      # measured on ViT-B/16: 42.5 ms with, 41.3 ms without -> off by default
-_SIDE = {}
-
-
-def set_overlap(on: bool) -> None:
-    """Toggle the two-stream dW / dX overlap (bench.py turns it off while timing individual kernels)."""
-    global OVERLAP_DW
-    _join_side()
-    OVERLAP_DW = bool(on)
-
-
-def _side_stream() -> "torch.cuda.Stream":
-    dev = torch.cuda.current_device()
-    st = _SIDE.get(dev)
-    if st is None:
-        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return st
-
-
-def _join_side() -> None:
-    """Order everything launched on the main stream from here on after the side-stream weight-gradient GEMMs."""
-    if OVERLAP_DW and _SIDE:
-        torch.cuda.current_stream().wait_stream(_side_stream())
 
 
 def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
@@ -157,12 +120,7 @@ def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Te
             return K.gemm_tn(dy16, x16, out=tw, beta=bw, want_dbias=True)
         return K.gemm_tn(dy16, x16, out=tw, beta=bw, dbias=tb, dbias_beta=bb)
 
-    if not OVERLAP_DW:
-        return run()
-    side = _side_stream()
-    side.wait_stream(torch.cuda.current_stream())       # dy16 / x16 are produced on the main stream
-    with torch.cuda.stream(side):
-        return run()
+    return run()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -211,9 +169,9 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
     qkv = K.gemm_nt(xn, wqkv_b, out_dtype=torch.bfloat16,
                     epilogue=EPI_BIAS if bqkv is not None else EPI_NONE, bias=bqkv)
     scale = dh ** -0.5
-    if meta.robust:
-        from . import sinkhorn
-        o, aux = sinkhorn.attn_fwd(qkv, B, N, H, dh, scale)
+    if meta.robust:                               # robust=True: softmax + Sinkhorn normalisation (utils.py:1025-1037), fused
+        o, lse, scal = K.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
+        aux = (lse, scal)
     else:
         o, aux = K.attn_fwd(qkv, B, N, H, dh, scale)
     if _RECORDING is not None:
@@ -241,13 +199,11 @@ def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int,
     do = K.gemm_nt(dy16, wo_t, out_dtype=torch.bfloat16)
     scale = dh ** -0.5
     if meta.robust:
-        from . import sinkhorn
-        dqkv = sinkhorn.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
+        dqkv = K.attn_sinkhorn_bwd(qkv, do, aux[0], aux[1], B, N, H, dh, scale)
     else:
         dqkv = K.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
     dwqkv, dbqkv = _dw_db(meta, dqkv, xn, wqkv, bqkv)
     dxn = K.gemm_nt(dqkv, wqkv_t, out_dtype=torch.bfloat16)
-    _join_side()
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
     dres = (dy32 if dy32 is not None else dy16) if residual else None
@@ -286,7 +242,6 @@ def mlp_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, meta: Bl
     du = K.gemm_nt(dy16, w2_t, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
     dw1, db1 = _dw_db(meta, du, xn, w1, b1)
     dxn = K.gemm_nt(du, w1_t, out_dtype=torch.bfloat16)
-    _join_side()
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
     dres = (dy32 if dy32 is not None else dy16) if residual else None
@@ -321,7 +276,6 @@ class EncoderStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, meta: BlockMeta, *params):
-        _require_softmax(meta)
         x2, B, N, D = _as_stream(x)
         depth = len(params) // PARAMS_PER_LAYER
         saved = []
@@ -343,16 +297,13 @@ class EncoderStackFn(torch.autograd.Function):
         d32 = dy.to(torch.float32).contiguous().reshape(B * N, D)
         d16 = None
         grads: List[Optional[Tensor]] = [None] * len(params)
-        # GRAD_STREAM_BF16: the residual-stream gradient travels between the halves in bf16 only (it is a GEMM operand
-        # in bf16 anyway); the fp32 copy is produced once, at the bottom of the stack, for autograd.
-        bf16_stream = GRAD_STREAM_BF16
+        # the residual-stream gradient travels between the halves in fp32 (it is the sum of 2 x depth branch gradients; a bf16
+        # stream was measured 1.9 % faster in round 1 and rejected: it rounds the running sum to 8 bits after every add)
         for i in reversed(range(depth)):
             p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             sa, sm = saved[i]
-            d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True,
-                                        want_f32=not bf16_stream)
-            d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0,
-                                         want_f32=(not bf16_stream) or i == 0)
+            d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True)
+            d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0)
             grads[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = ga + gm
             saved[i] = None                                  # free this block's activations early
             if meta.sink is not None:
@@ -366,7 +317,6 @@ class AttnHalfFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo):
-        _require_softmax(meta)
         x2, B, N, D = _as_stream(x)
         y, saved = attn_half_fwd(x2, B, N, meta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual=False)
         ctx.meta, ctx.params, ctx.saved_half, ctx.shape = meta, (ln_w, ln_b, wqkv, bqkv, wo, bo), saved, (B, N, D)

@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -29,6 +30,27 @@ def test_header_binding_and_library_agree(lib_path):
     for name in hdr:
         assert hasattr(handle, name), f"{name} declared in nrv.h but not exported"
     assert handle.nrv_abi_version() == _lib.ABI_VERSION
+    # and nothing else: every defined dynamic symbol of the library is declared in the header (no undeclared debug
+    # entry points, no kernel variants reachable only through environment switches)
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    host = [e for e in exported if not e.startswith("__hip_cuid_")]      # hipcc's per-translation-unit id objects
+    assert host == hdr, (set(host) ^ set(hdr))
+
+
+def test_product_has_no_environment_switches():
+    """Nothing in the shipped package or its HIP sources reads the environment to pick a kernel variant."""
+    pkg = os.path.join(ROOT, "noise_robust_vit_amd")
+    hits = []
+    for dp, _, fns in os.walk(pkg):
+        if "_obj" in dp or "__pycache__" in dp:
+            continue
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".hpp")):
+                text = open(os.path.join(dp, fn)).read()
+                if "getenv" in text or "os.environ" in text:
+                    hits.append(fn)
+    assert hits == [], hits
 
 
 def test_loader_sets_prototypes_and_reports_errors(lib_path):

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Debug: per-workgroup phase timing of the NT GEMM (NRV_GEMM_STAMPS=1).  Dev tool, GPU only."""
+"""Per-workgroup phase timing of the NT GEMM.  Dev tool, GPU only: needs the instrumented developer build
+(`python tools/build_dev.py stamps -DNRV_DEV_STAMPS`, built in the dev container; the product library has no stamps)."""
 import os, sys, ctypes
-os.environ["NRV_GEMM_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
-from noise_robust_vit_amd import kernels as K, _lib
+import _devlib
+from noise_robust_vit_amd import kernels as K
 from noise_robust_vit_amd._lib import *
 dev = torch.device("cuda:0")
-lib = _lib.load()
-lib.nrv_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+lib = _devlib.use_library("stamps")
+lib.nrv_dev_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 T = 50432
 def run(M, N, Kd, epi, odt, name):
     A = (torch.randn(M, Kd, device=dev) * .5).bfloat16(); B = (torch.randn(N, Kd, device=dev) * .5).bfloat16()
@@ -20,11 +21,9 @@ def run(M, N, Kd, epi, odt, name):
     f = lambda: K.gemm_nt(A, B, epilogue=epi, bias=bias if epi in (1, 2, 3) else None, aux=aux, aux_out=aux_out, out=out)
     for _ in range(3): f()
     torch.cuda.synchronize()
-    tile = int(os.environ.get("NRV_GEMM_TILE", "192"))
-    bm, bn = (256, 256) if tile == 256 else (192, 128)
-    nwg = -(-M // bm) * -(-N // bn)
+    nwg = min(-(-M // 256), -(-M // 320) if N == 768 else 1 << 30) * -(-N // 256)      # 320-row tiles on the N = 768 shapes
     buf = np.zeros(nwg * 5, dtype=np.uint64)
-    assert lib.nrv_debug_read_stamps(buf.ctypes.data, buf.size) == 0
+    assert lib.nrv_dev_read_stamps(buf.ctypes.data, buf.size) == 0
     s = buf.reshape(nwg, 5)
     t = s[:, :4].astype(np.float64) * 0.01     # 100 MHz -> us
     base = t[:, 0].min()
