@@ -75,6 +75,34 @@ __device__ __forceinline__ void gelu_both(float u, float& g, float& dg) {
     g = u * Phi;
     dg = fmaf(u, phi, Phi);
 }
+// four elements at once, written on vectors so that hipcc emits packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32:
+// two elements per issue slot; the epilogue that calls this is VALU-issue bound).  The 0.5 of Phi is folded into the
+// polynomial, |u| into the fma's source modifier, the sign select into one v_bfi (copysign).
+__device__ __forceinline__ void gelu_both4(f32x4_t u, f32x4_t& g, f32x4_t& dg) {
+    f32x4_t t, e;
+    const f32x4_t w = u * 0.84932180028801904f;                                  // sqrt(log2(e) / 2): w^2 = u^2/2 * log2 e
+    const f32x4_t w2 = w * w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[j] = __builtin_amdgcn_rcpf(fmaf(fabsf(u[j]), 0.3275911f * 0.70710678118654752f, 1.0f));
+        e[j] = __builtin_amdgcn_exp2f(-w2[j]);                                   // exp(-u^2 / 2): the negation is a source modifier
+    }
+    // h = erfc(|u| / sqrt 2) / 2 in [0, 0.5].  Phi = 1/2 + sign(u) (1/2 - h) is written 1/2 + copysign(h - 1/2, u): copysign
+    // ignores the sign of its first argument, so no operand has to be negated (hipcc spends a v_xor per element on a
+    // negated operand of a packed f32 instruction)
+    f32x4_t q = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+    q = q * t + (0.5f * 1.421413741f);
+    q = q * t + (0.5f * -0.284496736f);
+    q = q * t + (0.5f * 0.254829592f);
+    q = q * t;
+    const f32x4_t z = e * q + (-0.5f);
+    f32x4_t Phi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Phi[j] = 0.5f + __builtin_copysignf(z[j], u[j]);
+    const f32x4_t phi = e * 0.39894228040143268f;
+    g = u * Phi;
+    dg = u * phi + Phi;
+}
 __device__ __forceinline__ float gelu_grad(float u) {
     float Phi, phi;
     gelu_parts(u, Phi, phi);

@@ -100,11 +100,169 @@ __device__ __forceinline__ int remap_row(int m, int group, int group_stride, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Epilogue shared by both kernels.  acc[mi][ni] holds, for lane l: row  m = 16 mi + (l & 15),
-// columns n = 16 ni + 4 (l >> 4) + {0,1,2,3} of the wave's 128 x 64 block.
+// Epilogues.  acc[mi][ni] holds, for lane l: row  m = 16 mi + (l & 15), columns n = 16 ni + 4 (l >> 4) + {0,1,2,3} of
+// the wave's (16 MI) x 64 block.  A 16 x 64 slab goes through a wave-private LDS patch so that every global access is a
+// 16-byte, row-contiguous access.
+//
+// The epilogue is VALU-ISSUE bound (one wave64 VALU instruction per ~4.7 cycles per SIMD, two waves per SIMD: the round-1
+// epilogue times of 3.4 / 12.4 / 17.5 us per 256 x 256 tile are 2 x 735 / 2648 / 4014 instructions x 4.7 cycles), so
+// `epilogue_lin` spends no vector instruction on addresses: C, the epilogue operand and the gelu' stream are addressed
+// through buffer descriptors whose base is the wave's block; the per-lane offset (row within a pass, column chunk) is ONE
+// VGPR computed once, the row of each pass is a scalar soffset, and rows >= M / columns >= N are dropped by the
+// descriptor's range check (a pass whose first row is >= M is skipped by a scalar branch, so soffset never exceeds the
+// record count).  `epilogue_remap` keeps per-row pointer arithmetic for the one launch per step that scatters rows
+// (class-token slot of the patch embedding) or broadcasts the operand rows (positional table).
 // ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned rawx4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned rawx2_t;
+
 template <int EPI, bool OUT_F32, bool AUX_F32, int MI>
-__device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, const EpiParams& e,
+__device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], char* smem, const EpiParams& e,
+                                             int row_base /* global row of the wave's block (wave-uniform) */,
+                                             int col_base /* global col of the wave's block (wave-uniform) */,
+                                             int lane, int wave_u) {
+    const int rows_left = e.M - row_base, cols_left = e.N - col_base;
+    if (rows_left <= 0 || cols_left <= 0) return;                       // uniform: the whole block is outside
+    float* stg = reinterpret_cast<float*>(smem + wave_u * EPI_PATCH_BYTES);
+    const int wc_row = lane & 15, wg = lane >> 4;       // write side: row within slab, column group
+    constexpr int CW = OUT_F32 ? 4 : 8;                 // columns per lane on the read side: one 16-byte store
+    constexpr int V = CW / 4;                           // float4 pieces per lane
+    constexpr int LPR = 64 / CW;                        // lanes per 64-column row
+    constexpr int RPI = 64 / LPR;                       // rows covered per pass
+    constexpr int NIT = 16 / RPI;                       // passes per 16-row slab
+    const int rcol = lane % LPR, rrow = lane / LPR;
+    const bool col_ok = rcol * CW < cols_left;          // N % 8 == 0: a chunk is entirely inside or outside
+    const int rows_here = rows_left < MI * 16 ? rows_left : MI * 16;
+    const int cols_here = cols_left < 64 ? cols_left : 64;
+    constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
+    constexpr bool AUX32 = EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32;
+    constexpr int ES = OUT_F32 ? 4 : 2, AS = AUX32 ? 4 : 2;
+    constexpr int AW = CW * AS / 4;                     // dwords of the epilogue operand per lane and pass: 2, 4 or 8
+    constexpr int HALF = MI > 8 ? (MI + 3) / 4 : (MI + 1) / 2;      // operand-prefetch depth, bounded by the register file
+
+    // descriptors: base = the wave's block, records end with the last valid column of the last valid row
+    const int c_rs = (int)e.ldc * ES;
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(static_cast<char*>(e.C) + ((long long)row_base * e.ldc + col_base) * ES,
+                                                ((unsigned long long)(rows_here - 1) * e.ldc + cols_here) * ES);
+    const unsigned c_vo = col_ok ? (unsigned)(rrow * c_rs + rcol * CW * ES) : NRV_OOB;
+    const int a_rs = HAS_AUX ? (int)e.ld_aux * AS : 0;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(HAS_AUX ? static_cast<const char*>(e.aux) + ((long long)row_base * e.ld_aux + col_base) * AS : nullptr,
+                                                HAS_AUX ? ((unsigned long long)(rows_here - 1) * e.ld_aux + cols_here) * AS : 0ull);
+    const unsigned a_vo = (HAS_AUX && col_ok) ? (unsigned)(rrow * a_rs + rcol * CW * AS) : NRV_OOB;
+    const bool want_u = EPI == NRV_EPI_BIAS_GELU && e.aux_out != nullptr;
+    const int u_rs = want_u ? (int)e.ld_aux_out * 2 : 0;
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(want_u ? static_cast<char*>(e.aux_out) + ((long long)row_base * e.ld_aux_out + col_base) * 2 : nullptr,
+                                                want_u ? ((unsigned long long)(rows_here - 1) * e.ld_aux_out + cols_here) * 2 : 0ull);
+    const unsigned u_vo = (want_u && col_ok) ? (unsigned)(rrow * u_rs + rcol * CW * 2) : NRV_OOB;
+
+    f32x4_t bias4[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) bias4[v] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr bool HAS_BIAS = EPI == NRV_EPI_BIAS || EPI == NRV_EPI_BIAS_GELU || EPI == NRV_EPI_BIAS_RESIDUAL;
+    const bool add_bias = HAS_BIAS && e.bias != nullptr;                 // uniform
+    if (add_bias && col_ok) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) bias4[v] = *reinterpret_cast<const f32x4_t*>(e.bias + col_base + rcol * CW + 4 * v);
+    }
+
+#pragma unroll
+    for (int h0 = 0; h0 < MI; h0 += HALF) {
+        // the epilogue operand does not depend on the LDS transposition: issue the loads of a group of slabs up front
+        unsigned auxr[HAS_AUX ? HALF : 1][NIT][AW];
+        if (HAS_AUX) {
+#pragma unroll
+            for (int mh = 0; mh < HALF; ++mh) {
+                const int mi = h0 + mh;
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    if (mi < MI) {
+                        const int r0 = mi * 16 + RPI * i;                // first row of the pass (uniform)
+                        const int so = (r0 < rows_here ? r0 : 0) * a_rs;  // keep soffset inside the records; the lanes are dropped below
+                        const unsigned vo = r0 < rows_here ? a_vo : NRV_OOB;
+                        if (AW == 2) {
+                            const rawx2_t t = __builtin_amdgcn_raw_buffer_load_b64(ra, vo, so, 0);
+                            auxr[mh][i][0] = t[0]; auxr[mh][i][1] = t[1];
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < AW / 4; ++q) {
+                                const rawx4_t t = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + 16 * q, so, 0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) auxr[mh][i][4 * q + j] = t[j];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mh = 0; mh < HALF; ++mh) {
+            const int mi = h0 + mh;
+            if (mi < MI) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    *reinterpret_cast<f32x4_t*>(stg + wc_row * EPI_ROW_F32 + ni * 16 + wg * 4) = acc[mi][ni];
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    const int r = rrow + RPI * i;
+                    f32x4_t val[V];
+#pragma unroll
+                    for (int v = 0; v < V; ++v) val[v] = *reinterpret_cast<const f32x4_t*>(stg + r * EPI_ROW_F32 + rcol * CW + 4 * v);
+                    const int r0 = mi * 16 + RPI * i;                    // first row of the pass within the block (uniform)
+                    if (r0 < rows_here) {                                // scalar branch; later rows of the pass: range check
+                        unsigned pk[2 * V], pku[2 * V];
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            f32x4_t x = val[v];
+                            if (HAS_BIAS) x += bias4[v];
+                            if (EPI == NRV_EPI_BIAS_GELU) {
+                                // one erf/exp evaluation gives both gelu(u) (the output) and gelu'(u) (saved for the backward)
+                                f32x4_t dg;
+                                gelu_both4(x, x, dg);
+                                pku[2 * v] = pack_bf16x2(dg[0], dg[1]);
+                                pku[2 * v + 1] = pack_bf16x2(dg[2], dg[3]);
+                            }
+                            if (HAS_AUX) {
+                                f32x4_t a;
+                                if (AUX32) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) a[j] = __uint_as_float(auxr[mh][i][4 * v + j]);
+                                } else {
+                                    const unsigned a0 = auxr[mh][i][2 * v], a1 = auxr[mh][i][2 * v + 1];
+                                    a = f32x4_t{bf16lo_to_f32(a0), bf16hi_to_f32(a0), bf16lo_to_f32(a1), bf16hi_to_f32(a1)};
+                                }
+                                if (EPI == NRV_EPI_BIAS_RESIDUAL) x += a;
+                                else x *= a;
+                            }
+                            if (OUT_F32) {
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rawx4_t, x), rc, c_vo + 16 * v, r0 * c_rs, 0);
+                            } else {
+                                pk[2 * v] = pack_bf16x2(x[0], x[1]);
+                                pk[2 * v + 1] = pack_bf16x2(x[2], x[3]);
+                            }
+                        }
+                        if (!OUT_F32) {      // V == 2: one 16-byte store of 8 bf16
+                            const rawx4_t o = {pk[0], pk[1], pk[2 * V - 2], pk[2 * V - 1]};
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_vo, r0 * c_rs, 0);
+                        }
+                        if (EPI == NRV_EPI_BIAS_GELU && want_u) {
+                            if (V == 2) {
+                                const rawx4_t o = {pku[0], pku[1], pku[2 * V - 2], pku[2 * V - 1]};
+                                __builtin_amdgcn_raw_buffer_store_b128(o, ru, u_vo, r0 * u_rs, 0);
+                            } else {
+                                const rawx2_t o = {pku[0], pku[1]};
+                                __builtin_amdgcn_raw_buffer_store_b64(o, ru, u_vo, r0 * u_rs, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// per-row pointer arithmetic (row remap / operand row broadcast): the patch-embedding launch only
+template <int EPI, bool OUT_F32, bool AUX_F32, int MI>
+__device__ __forceinline__ void epilogue_remap(f32x4_t (&acc)[MI][4], char* smem, const EpiParams& e,
                                          int row_base /* global row of the wave's block */,
                                          int col_base /* global col of the wave's block */,
                                          int lane, int wave) {
@@ -238,11 +396,12 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[MI][4], char* smem, cons
 // stored at chunk position c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for the MFMA fragment
 // pattern (lane & 15 = row, lane >> 4 = chunk).
 // ---------------------------------------------------------------------------------------------
-template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
+template <typename C, int EPI, bool OUT_F32, bool AUX_F32, bool REMAP>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / C::WN, wc = wave - wr * C::WN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: descriptors, LDS bases and
+    const int wr = wave / C::WN, wc = wave - wr * C::WN;                 // the epilogue's row offsets stay in scalar registers
 
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
     // tile order: consecutive ids run concurrently on one XCD (xcd_remap).  With column groups of `gn` tiles the 32
@@ -360,7 +519,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 #ifdef NRV_DEV_STAMPS
     if (p.stamps) t2 = __builtin_amdgcn_s_memrealtime();
 #endif
-    epilogue<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
+    if (REMAP) epilogue_remap<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
+    else epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
 #ifdef NRV_DEV_STAMPS
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -382,7 +542,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
@@ -514,7 +675,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     }
     EpiParams e = p.e;
     e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
-    epilogue<NRV_EPI_NONE, true, true, 8>(acc, smem, e, m0 + wr * 128, n0 + wc * 64, lane, wave);
+    epilogue_lin<NRV_EPI_NONE, true, true, 8>(acc, smem, e, m0 + wr * 128, n0 + wc * 64, lane, wave);
 }
 
 // C = beta * C + sum_s slab[s]
@@ -561,9 +722,9 @@ int set_lds(KernelT k, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
+template <typename C, int EPI, bool OUT_F32, bool AUX_F32, bool REMAP>
 int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
-    static int attr = set_lds(gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32>, C::LDS);
+    static int attr = set_lds(gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32, REMAP>, C::LDS);
     if (attr != 0) return attr;
     const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
     p.tiles_n = tiles_n;
@@ -571,7 +732,7 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
 #ifdef NRV_DEV_STAMPS
     p.stamps = debug_stamp_buffer();
 #endif
-    hipLaunchKernelGGL((gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32, REMAP>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }
@@ -603,8 +764,11 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
     const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
-    if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32>(p, s);
-    return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
+    if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
+        return tc == 320 ? launch_nt_cfg<Cfg320, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s)
+                         : launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);
+    if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
+    return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32, false>(p, s);
 }
 
 int tn_splits(int64_t M, int64_t N, int64_t T) {
@@ -636,6 +800,9 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     if (!nrv_aligned16(A) || !nrv_aligned16(B) || !nrv_aligned16(C) || ((ldc * csz) & 15)) return NRV_ERR_ALIGN;
     if (lda * 2 * 256 >= 0x7fffffffll || ldb * 2 * 256 >= 0x7fffffffll) return NRV_ERR_SHAPE;
     if (out_group < 0 || (out_group > 0 && out_group_stride < out_group)) return NRV_ERR_SHAPE;
+    if ((out_group > 0 || aux_row_mod > 0) && epilogue_id != NRV_EPI_BIAS_RESIDUAL) return NRV_ERR_EPILOGUE;   // nrv.h: remap rides on that epilogue
+    // the epilogue addresses a wave's block (<= 160 rows) with 32-bit byte offsets
+    if (ldc * 4 * 320 >= 0x7fffffffll || ld_aux * 4 * 320 >= 0x7fffffffll || ld_aux_out * 2 * 320 >= 0x7fffffffll) return NRV_ERR_SHAPE;
     const bool need_aux = epilogue_id == NRV_EPI_BIAS_RESIDUAL || epilogue_id == NRV_EPI_DGELU;
     if (need_aux) {
         if (!aux) return NRV_ERR_EPILOGUE;

@@ -196,6 +196,50 @@ def test_gemm_nt_many_tiles(dev, M, N, K):
         assert out.reshape(M // G, G + 1, N)[:, 0].abs().max() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(257, 104, 72), (300, 576, 192), (129, 264, 64), (1, 8, 8), (321, 72, 136), (1000, 768, 768)])
+def test_gemm_nt_edge_tiles_write_nothing_outside(dev, M, N, K):
+    """The epilogue drops rows >= M and columns >= N through the buffer descriptor's range check (no per-lane address
+    test): every epilogue and output type writes exactly C[0:M, 0:N] of a padded allocation (sentinel rows before and
+    after, sentinel columns beyond N in every row, operands with their own leading dimensions)."""
+    k = _k()
+    from noise_robust_vit_amd._lib import EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU
+    A = rnd((M, K), dev, 70, 0.5)
+    B = rnd((N, K), dev, 71, 0.2)
+    bias = rnd((N,), dev, 72, 1.0, torch.float32)
+    acc = A.float() @ B.float().t()
+    PADR, PADC, S = 5, 24, 777.0
+    for odt in (torch.float32, torch.bfloat16):
+        for epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU):
+            big = torch.full((M + 2 * PADR, N + PADC), S, dtype=odt, device=dev)
+            out = big[PADR:PADR + M, :N]
+            aux = aux_out = None
+            ubig = None
+            if epi == EPI_BIAS_RESIDUAL:
+                aux = rnd((M, N + 16), dev, 73, 1.0, torch.float32)[:, :N]
+                ref = acc + bias + aux
+            elif epi == EPI_DGELU:
+                aux = rnd((M, N + 8), dev, 74, 1.0)[:, :N]
+                ref = acc * aux.float()
+            elif epi == EPI_BIAS_GELU:
+                ubig = torch.full((M + 2 * PADR, N + PADC), S, dtype=torch.bfloat16, device=dev)
+                aux_out = ubig[PADR:PADR + M, :N]
+                ref = torch.nn.functional.gelu(acc + bias)
+            elif epi == EPI_BIAS:
+                ref = acc + bias
+            else:
+                ref = acc
+            k.gemm_nt(A, B, epilogue=epi, bias=bias if epi in (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL) else None,
+                      aux=aux, aux_out=aux_out, out=out)
+            tol = 2 ** -7 if odt == torch.bfloat16 else 1e-5 * math.sqrt(K)
+            assert rel_err(out, ref) < tol + 1e-6, (epi, odt, rel_err(out, ref))
+            for b2 in (big, ubig):
+                if b2 is None:
+                    continue
+                guard = b2.clone().float()
+                guard[PADR:PADR + M, :N] = S
+                assert (guard == S).all(), f"epilogue {epi} {odt} wrote outside C[0:M, 0:N]"
+
+
 def test_gemm_nt_row_remap(dev):
     """class-token slot: result row m lands at (m // 196) * 197 + m % 196 + 1 (vit.py:341-342)."""
     k = _k()
