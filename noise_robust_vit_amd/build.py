@@ -32,8 +32,8 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP toolchain is required to build libnrv_hip.so")
 
 
-def _deps() -> list:
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+def _deps(csrc: str = CSRC) -> list:
+    hdrs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     hdrs.append(os.path.join(ROOT, "include", "nrv.h"))
     return hdrs
 
@@ -45,27 +45,30 @@ def _stale(target: str, srcs: list) -> bool:
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
-def _compile(src: str, force: bool, objdir: str = OBJ, extra: tuple = ()) -> str:
+def _compile(src: str, force: bool, objdir: str = OBJ, extra: tuple = (), csrc: str = CSRC) -> str:
     obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-    path = os.path.join(CSRC, src)
-    if force or _stale(obj, [path] + _deps()):
-        cmd = [_hipcc()] + FLAGS + list(extra) + ["-c", path, "-o", obj]
+    path = os.path.join(csrc, src)
+    if force or _stale(obj, [path] + _deps(csrc)):
+        flags = [f if f != "-I" + CSRC else "-I" + csrc for f in FLAGS]
+        cmd = [_hipcc()] + flags + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
     return obj
 
 
-def build(force: bool = False, verbose: bool = False, lib: str = LIB, objdir: str = OBJ, extra_flags: tuple = ()) -> str:
+def build(force: bool = False, verbose: bool = False, lib: str = LIB, objdir: str = OBJ, extra_flags: tuple = (),
+          csrc: str = CSRC, sources=None) -> str:
     """The product library by default.  `lib` / `objdir` / `extra_flags` exist for tools/build_dev.py, which compiles
     instrumented or experimental variants of the same sources into tools/_build/ (never loaded by the package)."""
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if len(srcs) != len(SOURCES):
-        raise RuntimeError(f"missing HIP sources: {sorted(set(SOURCES) - set(srcs))}")
+    want = list(sources or SOURCES)
+    srcs = [s for s in want if os.path.exists(os.path.join(csrc, s))]
+    if len(srcs) != len(want):
+        raise RuntimeError(f"missing HIP sources: {sorted(set(want) - set(srcs))}")
     with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, objdir, extra_flags), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, objdir, extra_flags, csrc), srcs))
     if force or _stale(lib, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -50,6 +50,8 @@ struct TileCfg {
     static_assert(NI == 4, "epilogue slab is 64 columns");
     static_assert(TBM * 8 % THREADS == 0 && TBN * 8 % THREADS == 0, "whole DMA instructions");
 };
+using Cfg128 = TileCfg<2, 4, 4, 4>;      // 128x256 and 192x256: row counts that leave a 256-row grid a fraction of a round short
+using Cfg192 = TileCfg<2, 4, 6, 4>;      // of the 256 CUs (MAE: 12544 rows x N 768 = 147 tiles of 256 rows, 198 of 192)
 using Cfg256 = TileCfg<2, 4, 8, 4>;
 using Cfg320 = TileCfg<2, 4, 10, 4>;
 constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
@@ -750,24 +752,35 @@ int device_cus() {
 
 int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
     (void)K;
-    // One workgroup per CU: the kernel takes ceil(tiles / CUs) rounds of one tile time each.  Pick the tile height
-    // with the smaller rounds x rows product; e.g. [50432 x 768]: 591 tiles of 256 rows = 3 rounds, 474 tiles of 320
-    // rows = 2 rounds (measured 0.140 -> 0.121 ms with the fp32-residual epilogue).  The taller tile carries a ~3 %
-    // register-pressure penalty, so it must win by more than that.
+#ifdef NRV_DEV_TILE
+    return NRV_DEV_TILE;         // tools/build_dev.py only: one fixed tile height for A/B runs
+#endif
+    // One workgroup per CU: the kernel takes ceil(tiles / CUs) rounds of one tile time each, and a tile's time grows with
+    // its height (MFMA work ~ rows; operand traffic ~ rows + 256).  Pick the height with the smallest rounds x cost;
+    // e.g. [50432 x 768]: 591 tiles of 256 rows = 3 rounds, 474 tiles of 320 rows = 2 rounds (0.140 -> 0.121 ms measured);
+    // [12544 x 768] (MAE encoder, 49 tokens): 147 tiles of 256 rows leave 43 % of the CUs idle, 198 tiles of 192 rows do not.
     const int64_t cus = device_cus();
     const int64_t tn = nrv_cdiv(N, 256);
-    const double c256 = (double)nrv_cdiv(nrv_cdiv(M, 256) * tn, cus) * 256.0;
-    const double c320 = (double)nrv_cdiv(nrv_cdiv(M, 320) * tn, cus) * 320.0 * 1.03;
-    return c320 < c256 ? 320 : 256;
+    static const int heights[4] = {256, 320, 192, 128};          // ties go to the earlier entry
+    static const double per_tile[4] = {256.0 + 64.0, (320.0 + 64.0) * 1.01, 192.0 + 64.0, 128.0 + 64.0};
+    int best = 256;
+    double best_cost = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        const double c = (double)nrv_cdiv(nrv_cdiv(M, heights[i]) * tn, cus) * per_tile[i];
+        if (i == 0 || c < best_cost * 0.999) { best = heights[i]; best_cost = c; }
+    }
+    return best;
 }
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
     const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
     if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
-        return tc == 320 ? launch_nt_cfg<Cfg320, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s)
+        return tc >= 320 ? launch_nt_cfg<Cfg320, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s)
                          : launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);
     if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
+    if (tc == 192) return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32, false>(p, s);
+    if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32, false>(p, s);
     return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32, false>(p, s);
 }
 

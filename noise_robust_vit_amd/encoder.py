@@ -37,53 +37,84 @@ PARAMS_PER_LAYER = 12   # ln1_w ln1_b wqkv bqkv wo bo ln2_w ln2_b w1 b1 w2 b2
 # parameter's version counter changes (i.e. once per optimizer step).
 # ----------------------------------------------------------------------------------------------
 class WeightCache:
-    """id(tensor) -> (weakref, version, data_ptr, bf16 W, bf16 W^T).  Dead entries are purged, so temporaries such as a
-    `torch.cat` of split projection weights (lucid_vit.Attention: to_q + to_kv) do not accumulate."""
+    """(id(owner), data_ptr, shape) -> (weakref(owner), version, bf16 W, bf16 W^T); owner = the tensor, or its base when
+    it is a view of a persistent buffer (lucid_vit.Attention's fused [to_q; to_kv] projection).  Dead entries are purged.
+
+    `derived` sources: fp32 buffers that are COPIES of parameters (the fused projection above) register a refresher; it
+    runs before `refresh_all()` re-stages the images and whenever `epoch` moved, so a copy never outlives an update of
+    its parameters through raw pointers (which leaves version counters untouched)."""
 
     def __init__(self) -> None:
         self._d = {}
         self._jobs = None
+        self._derived = []           # weak references to bound methods
+        self.epoch = 0
+
+    @staticmethod
+    def _owner(w: Tensor) -> Tensor:
+        return w._base if w._base is not None else w
 
     def get(self, w: Tensor, need_t: bool):
-        key = id(w)
+        owner = self._owner(w)
+        key = (id(owner), w.data_ptr(), tuple(w.shape))
         ent = self._d.get(key)
         ver = w._version
-        if ent is not None and ent[0]() is w and ent[1] == ver and ent[2] == w.data_ptr():
-            return ent[3], ent[4]
+        if ent is not None and ent[0]() is owner and ent[1] == ver:
+            return ent[2], ent[3]
         w2 = w.detach()
         if w2.dim() != 2:                       # Conv2d patch-embed weight [D, C, p, p] viewed as [D, C*p*p]
             w2 = w2.reshape(w2.shape[0], -1)
         wb, wt = K.cast_transpose(w2, need_t=True)
         if len(self._d) > 2048:
             self._d = {k: v for k, v in self._d.items() if v[0]() is not None}
-        self._d[key] = (weakref.ref(w), ver, w.data_ptr(), wb, wt)
+        self._d[key] = (weakref.ref(owner), ver, wb, wt)
         self._jobs = None
         return wb, wt
+
+    def add_derived(self, bound_method) -> None:
+        self._derived.append(weakref.WeakMethod(bound_method))
+
+    def _run_derived(self) -> None:
+        alive = []
+        for r in self._derived:
+            fn = r()
+            if fn is not None:
+                fn()
+                alive.append(r)
+        self._derived = alive
 
     def clear(self) -> None:
         self._d.clear()
         self._jobs = None
+        self.epoch += 1
 
     def refresh_all(self) -> None:
         """Re-stage every live entry IN PLACE with one batched launch (after an optimizer step that updated the fp32 masters
         through raw pointers: version counters and addresses are unchanged, so the entries stay valid afterwards)."""
+        self.epoch += 1
+        self._run_derived()                    # fp32 copies of parameters first: their images are re-staged below
         live = [(k, v) for k, v in self._d.items() if v[0]() is not None]
         if len(live) != len(self._d):
             self._d = dict(live)
             self._jobs = None
         key = tuple(k for k, _ in live)
-        jobs = getattr(self, "_jobs", None)
+        jobs = self._jobs
         if jobs is None or jobs[0] != key:
             srcs = []
-            for _, (ref, ver, ptr, wb, wt) in live:
+            for k, (ref, ver, wb, wt) in live:
                 w = ref().detach()
-                if w.data_ptr() != ptr or w._version != ver or not w.is_contiguous():
-                    self.clear()                 # something else changed: fall back to lazy re-staging
+                if w.data_ptr() != k[1] or w.numel() != wb.numel() or not w.is_contiguous():
+                    self.clear()                 # something else changed (or a partial view): fall back to lazy re-staging
                     return
                 srcs.append((w.reshape(wb.shape), wb, wt))
             jobs = (key, K.build_cast_jobs(srcs), srcs)
             self._jobs = jobs
         K.run_cast_jobs(jobs[1])
+        # the images are current again: entries whose source bumped its version meanwhile (derived copies) stay valid
+        for k, v in list(self._d.items()):
+            o = v[0]()
+            if o is not None:
+                self._d[k] = (v[0], o._version, v[2], v[3])
 
 
 WEIGHTS = WeightCache()
@@ -161,9 +192,13 @@ def _record(qkv: Tensor, aux, B: int, N: int, H: int, dh: int, scale: float, rob
 # attention half
 # ----------------------------------------------------------------------------------------------
 def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool):
-    """x fp32 [B*N, D] -> (y fp32 [B*N, D], saved)."""
+    """x fp32 [B*N, D] -> (y fp32 [B*N, D], saved).  `ln_w is None`: no LayerNorm in front of the projection (the bare
+    `MultiheadAttention.forward` of the reference's forked module, utils.py:741-751)."""
     H, dh = meta.heads, meta.dim_head
-    xn, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, meta.eps)
+    if ln_w is None:
+        xn, mean, rstd = K.cast_bf16(x), None, None
+    else:
+        xn, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, meta.eps)
     wqkv_b, _ = WEIGHTS.get(wqkv, True)
     wo_b, _ = WEIGHTS.get(wo, True)
     qkv = K.gemm_nt(xn, wqkv_b, out_dtype=torch.bfloat16,
@@ -203,6 +238,11 @@ def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int,
     else:
         dqkv = K.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
     dwqkv, dbqkv = _dw_db(meta, dqkv, xn, wqkv, bqkv)
+    if ln_w is None:                     # no LayerNorm: the projection's input gradient IS the result
+        if residual:
+            raise NrvError("a residual attention half needs its LayerNorm")
+        dx32 = K.gemm_nt(dqkv, wqkv_t, out_dtype=torch.float32)
+        return dx32, None, [None, None, dwqkv, dbqkv, dwo, dbo]
     dxn = K.gemm_nt(dqkv, wqkv_t, out_dtype=torch.bfloat16)
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
@@ -372,6 +412,13 @@ class PatchEmbedFn(torch.autograd.Function):
         S = n + cls_slot
         out = torch.empty(Bn * S, D, dtype=torch.float32, device=img.device)
         pos2 = pos.detach().reshape(-1, D).to(torch.float32)
+        if pos2.shape[0] != S:
+            # the GEMM epilogue reads the table through raw pointers (row = token index): a table of another grid would be
+            # read out of bounds or add the wrong positions (the reference's broadcast add raises for a learned table)
+            raise NrvError(f"positional table has {pos2.shape[0]} rows but the image gives {n} patches"
+                           f"{' + class token' if cls_slot else ''} = {S} tokens")
+        if C * patch * patch != weight[0].numel():
+            raise NrvError(f"patch features {C * patch * patch} != projection in_features {weight[0].numel()}")
         if cls_slot:
             K.gemm_nt(patches, wb, epilogue=EPI_BIAS_RESIDUAL, bias=bias.detach() if bias is not None else None,
                       aux=pos2[1:], aux_row_mod=n, out=out, out_group=n, out_group_stride=S, out_row_offset=1)

@@ -168,7 +168,17 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
     ld_aux = 0
     if aux is not None:
         _dev(aux, "aux")
-        _, _, ld_aux = _rows2d(aux, "aux")
+        arows, acols, ld_aux = _rows2d(aux, "aux")
+        # the epilogue reads aux through raw pointers: row m % aux_row_mod, or the (remapped) output row
+        need = aux_row_mod if aux_row_mod else (M if not out_group else (M - 1) // out_group * out_group_stride + (M - 1) % out_group + out_row_offset + 1)
+        if arows < need or acols < N:
+            raise NrvError(f"gemm_nt: aux is [{arows}, {acols}] but the epilogue reads rows < {need}, columns < {N}")
+    if out_group:
+        need = (M - 1) // out_group * out_group_stride + (M - 1) % out_group + out_row_offset + 1
+        if out.shape[0] < need:
+            raise NrvError(f"gemm_nt: out has {out.shape[0]} rows, the row remap writes up to row {need - 1}")
+    elif out.shape[0] < M or out.shape[1] < N:
+        raise NrvError(f"gemm_nt: out is {tuple(out.shape)}, result is [{M}, {N}]")
     ld_ao = 0
     if aux_out is not None:
         _bf16(aux_out, "aux_out")

@@ -13,8 +13,22 @@ import torch
 from torch import nn
 
 from ._lib import PATCH_P1P2C
-from .encoder import AttnHalfFn, BlockMeta, EncoderStackFn, MlpHalfFn, PatchEmbedFn
+from .encoder import WEIGHTS, AttnHalfFn, BlockMeta, EncoderStackFn, MlpHalfFn, PatchEmbedFn
 from .simple_vit import PatchUnfold, _pair
+
+
+class _FusedRowsFn(torch.autograd.Function):
+    """[wq; wkv] as a view of the owner's persistent fused buffer; backward splits the rows."""
+
+    @staticmethod
+    def forward(ctx, owner, wq, wkv):
+        ctx.rows = wq.shape[0]
+        buf = owner._refresh_fused()
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g[:ctx.rows], g[ctx.rows:]
 
 
 def _no_dropout(p: float) -> None:
@@ -59,10 +73,30 @@ class Attention(nn.Module):
         self.to_kv = nn.Linear(dim, inner * 2, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
         self._meta = BlockMeta(heads=heads, dim_head=dim_head, eps=self.norm.eps)
+        self._fused = None           # persistent fp32 [3*inner, dim] copy of [to_q.weight; to_kv.weight]
+        self._fused_key = None
+        WEIGHTS.add_derived(self._refresh_fused)
+
+    def _refresh_fused(self):
+        """Keep the fused projection current: rebuilt (two row-block copies, in place) only when a source changed --
+        version counters / addresses, or the weight cache's epoch for updates through raw pointers (optim.FusedAdamW)."""
+        wq, wkv = self.to_q.weight, self.to_kv.weight
+        key = (wq._version, wkv._version, wq.data_ptr(), wkv.data_ptr(), WEIGHTS.epoch)
+        if self._fused is None or self._fused.device != wq.device:
+            self._fused = torch.empty(wq.shape[0] + wkv.shape[0], wq.shape[1], dtype=torch.float32, device=wq.device)
+            self._fused_key = None
+        if self._fused_key != key:
+            with torch.no_grad():
+                self._fused[:wq.shape[0]].copy_(wq)
+                self._fused[wq.shape[0]:].copy_(wkv)
+            self._fused_key = key
+        return self._fused
 
     def layer_params(self):
-        # one [3*inner, dim] projection for the fused QKV GEMM; autograd splits the gradient back through the cat
-        wqkv = torch.cat([self.to_q.weight, self.to_kv.weight], dim=0)
+        # one [3*inner, dim] projection for the fused QKV GEMM: a persistent buffer whose bf16 images stay cached across
+        # forwards (a fresh torch.cat per call would be re-cast and re-transposed every time); _FusedRowsFn hands the
+        # gradient rows back to to_q / to_kv
+        wqkv = _FusedRowsFn.apply(self, self.to_q.weight, self.to_kv.weight)
         return [self.norm.weight, self.norm.bias, wqkv, None, self.to_out[0].weight, self.to_out[0].bias]
 
     def forward(self, x, attn_mask=None, memories=None):

@@ -65,7 +65,12 @@ class MAE(nn.Module):
 
     # -- forward ----------------------------------------------------------------------------------------------------
     def forward(self, img, rand_indices=None):
-        patches = self.to_patch(img).to(torch.float32)          # regression targets [b, n, p*p*c]
+        # regression targets [b, n, p*p*c] from the fp32 image ('b c (h p1) (w p2) -> b (h w) (p1 p2 c)', mae.py:59): index
+        # bookkeeping in PyTorch, NOT the bf16 unfold that feeds the projection GEMM -- the targets are not rounded
+        p = self.to_patch.patch_height
+        bb, cc, hh, ww = img.shape
+        patches = (img.detach().to(torch.float32).reshape(bb, cc, hh // p, p, ww // p, p)
+                   .permute(0, 2, 4, 3, 5, 1).reshape(bb, (hh // p) * (ww // p), p * p * cc))
         b, n = patches.shape[0], patches.shape[1]
         n_drop = int(self.masking_ratio * n)
         if rand_indices is None:

@@ -56,13 +56,29 @@ class FusedAdamW:
         self.step_count += 1
         if max_norm and max_norm > 0:
             K.sumsq(self.grad, self.gnorm_sq, self._ws)
-        K.adamw_flat(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
-                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
-                     self.gnorm_sq if max_norm and max_norm > 0 else None, float(max_norm or 0.0))
+        # parameters without a gradient this step are skipped like torch.optim.AdamW skips `p.grad is None` (no weight decay,
+        # no moment update): the flat buffers are walked in the ranges between their slots (normally ONE range)
+        for lo, hi in self._active_ranges():
+            K.adamw_flat(self.param[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                         self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                         self.step_count, self.gnorm_sq if max_norm and max_norm > 0 else None, float(max_norm or 0.0))
         # the parameters changed through raw pointers: their version counters did not move, so the bf16 weight images
         # (encoder.WeightCache, keyed on the version) are re-staged explicitly -- all of them in one batched launch
         from .encoder import WEIGHTS
         WEIGHTS.refresh_all()
+
+    def _active_ranges(self):
+        skip = sorted(self.reducer.slot(p) for p in self.reducer.params_without_grad())
+        if not skip:
+            return [(0, self.grad.numel())]
+        out, cur = [], 0
+        for o, n in skip:
+            if o > cur:
+                out.append((cur, o))
+            cur = o + (n + 3) // 4 * 4
+        if cur < self.grad.numel():
+            out.append((cur, self.grad.numel()))
+        return out
 
     def grad_norm(self) -> torch.Tensor:
         """Global gradient norm seen by the last clipped step (device scalar; reading it synchronises)."""

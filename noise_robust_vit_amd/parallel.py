@@ -31,12 +31,22 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, model: torch.nn.Module, world: int, bucket_mib: float = 64.0,
-                 process_group=None, attach: bool = True) -> None:
+                 process_group=None, attach: bool = True, sync_params: bool = True,
+                 force_collectives: bool = False) -> None:
+        """`sync_params`: broadcast rank 0's parameters and buffers at construction, as DistributedDataParallel does
+        (examples/CIFAR100.py:206-208 wraps the model in DDP): replicas start identical whatever each rank's seed was.
+        `force_collectives`: issue every bucket's all-reduce even when world == 1 (a single-GPU RCCL process group
+        exercises exactly the calls, stream ordering and buffer slicing of the multi-GPU step)."""
         self.world = world
         self.pg = process_group
+        self.force = bool(force_collectives)
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
+        if sync_params and world > 1 and dist.is_initialized():
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, src=0, group=process_group)
         # backward order: the reverse of registration order (head ... first encoder layer ... patch embed)
         order = list(reversed(params))
         dev = params[0].device
@@ -83,6 +93,11 @@ class GradReducer:
         """The trainable parameters, registration order."""
         return list(self._params)
 
+    def params_without_grad(self):
+        """Parameters that received no gradient in the step just finished (valid between finish_step and begin_step):
+        torch.optim.AdamW skips those entirely (no weight decay, no moment update), and so does optim.FusedAdamW."""
+        return [p for p in self._params if id(p) not in self._ready]
+
     def slot(self, p: torch.Tensor):
         """(offset, numel) of p's gradient in `flat` (optim.FusedAdamW lays its parameter / moment buffers out the same way)."""
         return self._slot[id(p)]
@@ -117,7 +132,7 @@ class GradReducer:
 
     def _launch(self, b: int) -> None:
         self._launched[b] = True
-        if self.world <= 1 or not dist.is_initialized():
+        if (self.world <= 1 and not self.force) or not dist.is_initialized():
             return
         s, e, _ = self.buckets[b]
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
@@ -142,7 +157,7 @@ class GradReducer:
         for w in self._works:
             w.wait()
         self._works = []
-        if self.world > 1 and not self._avg_native and dist.is_initialized():
+        if (self.world > 1 or self.force) and not self._avg_native and dist.is_initialized():
             self.flat.mul_(1.0 / self.world)
 
     def bucket_bytes(self) -> List[int]:

@@ -135,7 +135,7 @@ class SimpleViT(nn.Module):
         self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, robust)
         self.to_latent = nn.Identity()
         self.linear_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
-        self._pos = None
+        self._pos = {}
         self._sink = None
 
     def attach_grad_sink(self, sink) -> None:
@@ -143,15 +143,24 @@ class SimpleViT(nn.Module):
         self._sink = sink
         self.transformer.attach_grad_sink(sink)
 
-    def positional_table(self, device) -> torch.Tensor:
-        if self._pos is None or self._pos.device != device:
+    def positional_table(self, device, grid=None) -> torch.Tensor:
+        """sincos table of the patch grid `grid` (default: the constructor's), built once per (grid, device).  The
+        reference recomputes it from the ACTUAL patch grid on every forward (simple_vit.py:141-143), so any image size
+        divisible by the patch works there; here each grid seen gets its own cached constant."""
+        grid = tuple(self.grid if grid is None else grid)
+        key = (grid, str(device))
+        tab = self._pos.get(key)
+        if tab is None:
             dim = self.to_patch_embedding[1].weight.shape[0]
-            self._pos = sincos_table_2d(self.grid[0], self.grid[1], dim, device=device)
-        return self._pos
+            tab = self._pos[key] = sincos_table_2d(grid[0], grid[1], dim, device=device)
+        return tab
 
     def forward(self, img):
         lin = self.to_patch_embedding[1]
-        x = PatchEmbedFn.apply(img, lin.weight, lin.bias, self.positional_table(img.device), None,
+        if img.dim() != 4 or img.shape[2] % self.patch or img.shape[3] % self.patch:
+            raise ValueError(f"expected [B, C, H, W] with H and W divisible by the patch size {self.patch}, got {tuple(img.shape)}")
+        grid = (img.shape[2] // self.patch, img.shape[3] // self.patch)
+        x = PatchEmbedFn.apply(img, lin.weight, lin.bias, self.positional_table(img.device, grid), None,
                                self.patch, PATCH_P1P2C, self._sink)
         x = self.transformer(x)
         x = x.mean(dim=1)                      # pooling + head stay in PyTorch-ROCm (SURVEY.md K8: 0.004 % of FLOPs)

@@ -66,8 +66,11 @@ class TrainConfig:
 class Trainer:
     """One process per GPU.  `reducer` (parallel.GradReducer) is None for single-GPU runs."""
 
-    def __init__(self, model: torch.nn.Module, cfg: TrainConfig, reducer=None) -> None:
+    def __init__(self, model: torch.nn.Module, cfg: TrainConfig, reducer=None, compute_loss=None) -> None:
+        """`compute_loss(model, x, y) -> scalar` replaces the classification loss (e.g. `lambda m, x, y: m(x)` for the MAE
+        wrapper, whose forward returns its reconstruction loss, mae.py:117-118)."""
         self.model, self.cfg = model, cfg
+        self.compute_loss = compute_loss
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params
         on_gpu = all(p.is_cuda for p in params)
@@ -94,7 +97,9 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.begin_step()
         c = self.cfg
-        if c.cutmix_prob > 0.0 and self.rng.random() < c.cutmix_prob:
+        if self.compute_loss is not None:
+            loss = self.compute_loss(self.model, x, y)
+        elif c.cutmix_prob > 0.0 and self.rng.random() < c.cutmix_prob:
             # CutMix as in the reference harness (CIFAR100.py:119-137): paste a box from a permuted batch, mix the losses
             perm = torch.randperm(x.shape[0], device=x.device)
             lam = float(self.rng.beta(c.cutmix_beta, c.cutmix_beta))
@@ -135,3 +140,31 @@ class Trainer:
         loss = self.forward_backward(x, y)
         self.optimizer_step()
         return loss
+
+    @torch.no_grad()
+    def eval_step(self, x: torch.Tensor, y: torch.Tensor, process_group=None) -> torch.Tensor:
+        """One evaluation batch as the reference harness does it (examples/CIFAR100.py:148-163): top-1 accuracy of this
+        rank's shard, summed onto rank 0 with ONE scalar `reduce` (the C2 collective of SURVEY.md §8e).  Returns the
+        accuracy tensor after the reduce: on rank 0 the SUM over ranks (the reference divides by world_size when it logs,
+        `after_eval_epoch`), elsewhere this rank's own value."""
+        import torch.distributed as dist
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            preds = self.model(x)
+        finally:
+            self.model.train(was_training)
+        accu = preds.argmax(1).eq(y).float().mean()
+        if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            dist.reduce(accu, dst=0, group=process_group)
+        return accu
+
+    def evaluate(self, batches, process_group=None) -> float:
+        """Mean top-1 accuracy over `batches` of (x, y) and over ranks -- meaningful on rank 0 (CIFAR100.py:142-163)."""
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        total, count = 0.0, 0
+        for x, y in batches:
+            total += self.eval_step(x, y, process_group).item()
+            count += 1
+        return total / max(count, 1) / world

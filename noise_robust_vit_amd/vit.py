@@ -62,13 +62,22 @@ class MultiheadAttention(nn.Module):
     def attn_params(self):
         return [self.in_proj_weight, self.in_proj_bias, self.out_proj.weight, self.out_proj.bias]
 
-    def forward(self, query, key=None, value=None, need_weights=False, **kw):
+    def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=False, attn_mask=None, **kw):
+        """Self-attention `forward(x, x, x, need_weights=False) -> (out, None)` (utils.py:741-751,594-597; the call site is
+        vit.py:124): packed QKV projection + bias -> fused softmax (or Sinkhorn, robust=True) attention -> out_proj + bias,
+        all in libnrv_hip.so.  `batch_first=False` takes / returns [S, B, E] like torch's module."""
         if (key is not None and key is not query) or (value is not None and value is not query):
             raise NotImplementedError("self-attention only (query is key is value), as EncoderBlock calls it")
         if need_weights:
-            raise NotImplementedError("the fused kernel never materialises attention weights")
-        raise NotImplementedError("stand-alone MultiheadAttention.forward (without the block's LayerNorm) is not part "
-                                  "of the hot path; call EncoderBlock / Encoder / VisionTransformer")
+            raise NotImplementedError("the fused kernel never materialises attention weights (use recorder.Recorder)")
+        if key_padding_mask is not None or attn_mask is not None:
+            raise NotImplementedError("attention masks are outside the encoder hot path")
+        if self.training:
+            _no_dropout(self.dropout, "attention dropout")
+        x = query if self.batch_first else query.transpose(0, 1)
+        meta = BlockMeta(heads=self.num_heads, dim_head=self.head_dim, eps=0.0, robust=bool(self.robust))
+        out = AttnHalfFn.apply(x, meta, None, None, *self.attn_params())
+        return (out if self.batch_first else out.transpose(0, 1)), None
 
 
 class MLPBlock(nn.Sequential):

@@ -74,7 +74,7 @@ def mae_forward(sd: Dict[str, Tensor], img: Tensor, rand_indices: Tensor, *, pat
     demb = sd["decoder_pos_emb.weight"]
     dec = dec + demb[unmasked]
     mask_tokens = sd["mask_token"][None, None, :].expand(B, num_masked, -1) + demb[masked]
-    full = torch.zeros(B, n, dec.shape[-1])
+    full = torch.zeros(B, n, dec.shape[-1], dtype=dec.dtype)
     full[br, unmasked] = dec
     full[br, masked] = mask_tokens
     out = lucid_transformer(full, sd, "decoder.", dec_heads, dim_head, Q)

@@ -163,7 +163,7 @@ def simple_vit_forward(sd: Dict[str, Tensor], img: Tensor, *, patch_size: int, h
     dim = wp.shape[0]
     patches = patchify_p1p2c(Q(img), p, p)
     x = patches @ Q(wp).t() + bp
-    x = x + posemb_sincos_2d(h, w, dim)
+    x = x + posemb_sincos_2d(h, w, dim).to(x.dtype)      # simple_vit.py:28: pe.type(dtype)
     if capture is not None:
         capture["embed"] = x.clone()
     x = transformer_forward(x, sd, heads=heads, dim_head=dim_head, robust=robust,

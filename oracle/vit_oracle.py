@@ -71,13 +71,16 @@ def mha_self_attention(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out
 
 
 def encoder_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, robust: bool, Q: _Q,
-                  eps: float = 1e-6) -> Tensor:
-    """EncoderBlock.forward, vit.py:118-130 (dropout p=0)."""
+                  eps: float = 1e-6, capture: Optional[dict] = None, tag: str = "") -> Tensor:
+    """EncoderBlock.forward, vit.py:118-130 (dropout p=0).  `capture[tag + ".attn_out"]` receives the residual stream
+    after the attention half (vit.py:126), for the per-half localisation in tests/test_model_gpu.py."""
     a = Q(layer_norm(x, sd[pfx + "ln_1.weight"], sd[pfx + "ln_1.bias"], eps))
     a = mha_self_attention(a, sd[pfx + "self_attention.in_proj_weight"], sd[pfx + "self_attention.in_proj_bias"],
                            sd[pfx + "self_attention.out_proj.weight"], sd[pfx + "self_attention.out_proj.bias"],
                            heads, robust, Q)
     x = a + x
+    if capture is not None:
+        capture[tag + ".attn_out"] = x.detach().clone()
     y = Q(layer_norm(x, sd[pfx + "ln_2.weight"], sd[pfx + "ln_2.bias"], eps))
     u = y @ Q(sd[pfx + "mlp.0.weight"]).t() + sd[pfx + "mlp.0.bias"]
     h = Q(gelu_erf(u))
@@ -97,10 +100,10 @@ def vit_forward(sd: Dict[str, Tensor], img: Tensor, *, patch_size: int, num_head
     x = torch.cat([sd["class_token"].expand(B, -1, -1), x], dim=1)
     x = x + sd["encoder.pos_embedding"]
     if capture is not None:
-        capture["embed"] = x.clone()
+        capture["embed"] = x.detach().clone()
     i = 0
     while f"encoder.layers.encoder_layer_{i}.ln_1.weight" in sd:
-        x = encoder_block(x, sd, f"encoder.layers.encoder_layer_{i}.", num_heads, robust, Q, eps)
+        x = encoder_block(x, sd, f"encoder.layers.encoder_layer_{i}.", num_heads, robust, Q, eps, capture, f"layer{i}")
         if capture is not None:
             capture[f"layer{i}.out"] = x.detach().clone()
         i += 1

@@ -79,3 +79,89 @@ def test_two_ranks_on_one_gpu_match_single_process(dev, tmp_path):
         if k.startswith("g.") or k.startswith("w."):
             a, b = torch.tensor(one[k]), torch.tensor(two[k])
             assert (a - b).abs().max() <= 2e-2 * a.abs().max() + 2e-5, k
+
+
+RCCL_WORKER = r"""
+import os, sys, json, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from noise_robust_vit_amd import VisionTransformer
+from noise_robust_vit_amd.parallel import GradReducer
+from noise_robust_vit_amd.train import Trainer, TrainConfig
+use_rccl = sys.argv[3] == "rccl"
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+if use_rccl:
+    # one-rank RCCL process group on the one GPU of the box: the backend, device binding, AVG reduce op, async work
+    # handles on slices of the flat buffer and the stream ordering against the hand-scheduled backward are exactly
+    # those of the 8-GPU step (bench.py, parallel.py); only the peer count differs
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+torch.manual_seed(0)
+m = VisionTransformer(image_size=32, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10)
+torch.nn.init.normal_(m.heads.head.weight, std=0.02)
+m = m.to(dev).train()
+red = GradReducer(m, 1, bucket_mib=0.5, force_collectives=True) if use_rccl else None
+ncalls = [0]
+if use_rccl:
+    assert dist.get_backend() == "nccl" and red._avg_native
+    orig = dist.all_reduce
+    def counted(t, *a, **k):
+        assert t.is_cuda and k.get("async_op") and k.get("op") == dist.ReduceOp.AVG
+        ncalls[0] += 1
+        return orig(t, *a, **k)
+    dist.all_reduce = counted
+tr = Trainer(m, TrainConfig(lr=1e-3, grad_max_norm=5.0), red)
+g = torch.Generator().manual_seed(7)
+x = torch.randn(8, 3, 32, 32, generator=g).to(dev); y = torch.randint(0, 10, (8,), generator=g).to(dev)
+losses = [tr.step(x, y).item() for _ in range(3)]
+tr.forward_backward(x, y)
+acc = tr.eval_step(x, y).item()
+torch.cuda.synchronize()
+out = {"loss": losses, "acc": acc, "nbuckets": len(red.buckets) if red else 0, "ncalls": ncalls[0]}
+for k, p in m.named_parameters():
+    out["g." + k] = p.grad.detach().float().cpu().reshape(-1).tolist()[:256]
+    out["w." + k] = p.detach().float().cpu().reshape(-1).tolist()[:256]
+json.dump(out, open(sys.argv[2], "w"))
+if use_rccl:
+    dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_rccl_process_group_on_one_gpu_matches_plain_run(dev, tmp_path):
+    """The `nccl` (= RCCL) branch of the data-parallel step on real hardware: a one-rank process group with
+    `force_collectives` issues every bucket's all_reduce(AVG, async_op=True) on its flat-buffer slice while the HIP
+    backward continues; gradients, parameters and losses equal the run without a process group BIT FOR BIT."""
+    import json
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    outs = {}
+    for mode in ("plain", "rccl"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = tmp_path / f"{mode}.json"
+        r = subprocess.run([sys.executable, str(script), ROOT, str(out), mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[mode] = json.load(open(out))
+    a, b = outs["plain"], outs["rccl"]
+    assert b["nbuckets"] > 1 and b["ncalls"] == 4 * b["nbuckets"]       # 3 steps + 1 forward_backward, every bucket every time
+    assert a["loss"] == b["loss"] and a["acc"] == b["acc"]
+    for k in a:
+        if k.startswith(("g.", "w.")):
+            assert a[k] == b[k], k
+
+
+def test_bench_under_the_distributed_launcher_one_rank(dev, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (the driver's launch line at N = 1): the
+    launcher path -- env rendezvous, RCCL init with device_id, barriers, MAX-reduce of the elapsed time, collectives in
+    the step -- runs end to end and prints one JSON line."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--arch", "vit_s_16", "--batch", "32", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["collectives"] == "rccl all_reduce(AVG) per 64 MiB bucket, forced at world 1"

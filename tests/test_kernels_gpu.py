@@ -207,7 +207,7 @@ def test_gemm_nt_edge_tiles_write_nothing_outside(dev, M, N, K):
     B = rnd((N, K), dev, 71, 0.2)
     bias = rnd((N,), dev, 72, 1.0, torch.float32)
     acc = A.float() @ B.float().t()
-    PADR, PADC, S = 5, 24, 777.0
+    PADR, PADC, S = 5, 24, 512.0       # exactly representable in bf16
     for odt in (torch.float32, torch.bfloat16):
         for epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU):
             big = torch.full((M + 2 * PADR, N + PADC), S, dtype=odt, device=dev)
@@ -316,7 +316,15 @@ def attn_ref(qkv, B, N, H, dh, scale):
     return o.permute(0, 2, 1, 3).reshape(B * N, H * dh), torch.logsumexp(s, dim=-1)
 
 
-@pytest.mark.parametrize("B,N,H", [(8, 4, 3), (2, 196, 3), (2, 197, 2), (3, 49, 2), (1, 256, 1), (2, 33, 1), (1, 1, 1)])
+# every key-tile template instantiation NT in {2, 4, 6, 8, 10, 12, 13, 14, 16} runs, each with a partial last tile and
+# (even NT reached from an odd tile count) a fully padded trailing tile: N = 65 / 81 -> NT 6, 100 / 113 -> 8, 129 / 160 -> 10,
+# 177 -> 12, 196 / 197 -> 13, 209 / 224 -> 14, 225 / 256 -> 16
+ATTN_SHAPES = [(8, 4, 3), (2, 196, 3), (2, 197, 2), (3, 49, 2), (1, 256, 1), (2, 33, 1), (1, 1, 1),
+               (2, 65, 1), (1, 81, 2), (1, 100, 2), (1, 113, 1), (2, 129, 1), (1, 160, 1), (1, 177, 2), (1, 209, 1), (1, 224, 2),
+               (1, 225, 1)]
+
+
+@pytest.mark.parametrize("B,N,H", ATTN_SHAPES)
 def test_attention_fwd_bwd(dev, B, N, H):
     k = _k()
     dh = 64
@@ -360,7 +368,7 @@ def sinkhorn_ref(qkv, B, N, H, dh, scale):
     return (P @ v).permute(0, 2, 1, 3).reshape(B * N, H * dh), P
 
 
-@pytest.mark.parametrize("B,N,H", [(8, 4, 3), (2, 196, 3), (2, 197, 2), (3, 49, 2), (1, 256, 1), (2, 33, 1), (1, 1, 1)])
+@pytest.mark.parametrize("B,N,H", ATTN_SHAPES)
 def test_sinkhorn_attention_fwd_bwd(dev, B, N, H):
     """robust=True attention (softmax + 3 x (row, column) + row normalisation) against the plain fp32 definition."""
     k = _k()
@@ -457,7 +465,7 @@ def test_cast_transpose_batched_matches_single(dev):
             assert torch.equal(wt, w.to(torch.bfloat16).t().contiguous())
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 49, 2), (1, 256, 1), (2, 5, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 49, 2), (1, 256, 1), (2, 5, 1), (1, 65, 1), (1, 100, 1), (1, 129, 2), (1, 177, 1), (1, 224, 1)])
 def test_attention_probs_export(dev, B, N, H):
     """nrv_attn_probs (introspection): exp(scale q.k - lse) equals torch.softmax on the same bf16 q, k; for the Sinkhorn
     kernel the saved scalings turn it into the reference's normalised matrix (sinkhorn_ref)."""

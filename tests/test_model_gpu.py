@@ -2,10 +2,15 @@
   (1) the golden fixtures recorded from the reference itself (tests/golden, SimpleViT path), and
   (2) the CPU oracle (oracle/, fp32) on seeded inputs, plus its bf16-emulating mode.
 
-Stated tolerances (DESIGN.md "Numerics"):  the hot path feeds bf16 operands to fp32-accumulating MFMAs,
-so against the fp32 reference the logits agree to LOGIT_TOL_FP32REF (max |d| / max |ref|); against the oracle
-evaluated with the same bf16 operand rounding they agree to 1e-3 (north-star tolerance), which is the check
-that separates a wrong kernel from operand rounding.
+Stated tolerances (DESIGN.md "Numerics"):  the hot path feeds bf16 operands to fp32-accumulating MFMAs, so the
+north-star "1e-3 relative to the fp32 CPU reference" is not reachable against an fp32 reference (every GEMM output
+carries ~1.6e-3 of operand-rounding noise); the ACHIEVED tolerance is the contract and every bound below is <= 2x
+what was measured on MI355X for that configuration (max |d| / max |ref| on the logits):
+    SimpleViT (mean pooling)         vs fp32 reference <= 6e-3,   vs the bf16-emulating oracle <= 1e-3 (north-star)
+    VisionTransformer (class token)  per case in VT_CASES (<= 1.2e-2 vs fp32; 1e-3 ... 8e-3 vs the emulating oracle)
+    gradients                        per-parameter relative L2 <= 1e-2 (SimpleViT) / per case (VT), cosine >= 0.999
+The comparison with the oracle evaluated with the same bf16 rounding points separates a wrong kernel from operand
+rounding; `test_vision_transformer_stage_localisation` shows per stage that what is left is rounding-boundary flips.
 """
 import numpy as np
 import pytest
@@ -13,11 +18,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL_FP32REF = 2e-2      # bf16 operands vs fp32 reference, max-norm relative
-LOGIT_TOL_EMULATED = 1e-3     # same rounding points as the kernels (north-star tolerance)
-LOSS_TOL_FP32REF = 5e-3
-GRAD_RELL2_TOL = 3e-2         # per-parameter relative L2 vs fp32 autograd of the oracle (bf16 path)
+LOGIT_TOL_FP32REF = 6e-3      # SimpleViT, bf16 operands vs fp32 reference, max-norm relative (measured 6.4e-4 ... 2.9e-3)
+LOGIT_TOL_EMULATED = 1e-3     # same rounding points as the kernels (north-star tolerance; measured 4.8e-6 ... 6.9e-4)
+LOSS_TOL_FP32REF = 2e-3       # measured <= 2.7e-4 ... 9e-4
+GRAD_RELL2_TOL = 1e-2         # per-parameter relative L2 vs fp32 autograd of the oracle (measured worst 4.4e-3)
 GRAD_COS_TOL = 0.999
+BRANCH_TOL_FP32REF = 1.2e-2   # a single half's OUTPUT (no residual stream to dilute it) vs fp32: bf16 operands, measured <= 6e-3
 
 
 def relmax(a, b):
@@ -29,7 +35,8 @@ def load_npz(path):
     return {k: torch.from_numpy(v) for k, v in np.load(path).items()}
 
 
-def check_grads(model, ref_grads, prefix=""):
+def check_grads(model, ref_grads, prefix="", tol=None):
+    tol = GRAD_RELL2_TOL if tol is None else tol
     worst = (0.0, None)
     for name, p in model.named_parameters():
         assert p.grad is not None, f"no grad for {name}"
@@ -42,7 +49,7 @@ def check_grads(model, ref_grads, prefix=""):
         cos = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
         if rel > worst[0]:
             worst = (rel, name)
-        assert rel < GRAD_RELL2_TOL and cos > GRAD_COS_TOL, f"{name}: rel-L2 {rel:.3e} cos {cos:.6f}"
+        assert rel < tol and cos > GRAD_COS_TOL, f"{name}: rel-L2 {rel:.3e} cos {cos:.6f}"
     return worst
 
 
@@ -108,8 +115,9 @@ def test_standalone_attention_and_feedforward_modules(dev):
     att, ff = att.to(dev), ff.to(dev)
     xd = x.to(dev).requires_grad_(True)
     out_a, out_f = att(xd), ff(xd)
-    assert relmax(out_a, ref_a) < LOGIT_TOL_FP32REF, relmax(out_a, ref_a)
-    assert relmax(out_f, ref_f) < LOGIT_TOL_FP32REF, relmax(out_f, ref_f)
+    print(f"stand-alone Attention {relmax(out_a, ref_a):.3e}, FeedForward {relmax(out_f, ref_f):.3e} vs fp32 oracle")
+    assert relmax(out_a, ref_a) < BRANCH_TOL_FP32REF, relmax(out_a, ref_a)
+    assert relmax(out_f, ref_f) < BRANCH_TOL_FP32REF, relmax(out_f, ref_f)
     w = torch.randn(4, 50, 192)
     (ref_a * w).sum().backward()
     ga = xr.grad.clone(); xr.grad = None
@@ -118,17 +126,26 @@ def test_standalone_attention_and_feedforward_modules(dev):
     assert rel < GRAD_RELL2_TOL, rel
 
 
-@pytest.mark.parametrize("cfg", [dict(image_size=32, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10),
-                                 dict(image_size=64, patch_size=16, num_layers=1, num_heads=2, hidden_dim=128, mlp_dim=256, num_classes=7),
-                                 # ViT-L/16 geometry (BASELINE.json configs[3]): 16 heads, D 1024, M 4096, 197 tokens; 2 of its 24 layers
-                                 dict(image_size=224, patch_size=16, num_layers=2, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=11)])
-def test_vision_transformer_against_oracle(dev, cfg):
-    """torchvision-style VisionTransformer (class token, learned positions, biased in/out projections, final LN).
-    Parity unpinned by the reference (its forward cannot run): the oracle is pinned against
-    torch.nn.MultiheadAttention in tests/test_oracle_vit.py."""
+VT_CASES = {
+    # name: (constructor arguments, batch, bound vs fp32 oracle, bound vs bf16-emulating oracle, bound on worst gradient rel-L2)
+    # Bounds are <= 2x the values measured on MI355X (DESIGN.md "Numerics" lists the measurements); the north-star 1e-3
+    # is met against the emulating oracle only where mean pooling or many tokens average the rounding-boundary flips.
+    "d192_l2_n5": (dict(image_size=32, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10), 5,
+                   1.2e-2, 3e-3, 1.8e-2),
+    "d128_l1_n17": (dict(image_size=64, patch_size=16, num_layers=1, num_heads=2, hidden_dim=128, mlp_dim=256, num_classes=7), 5,
+                    1.1e-2, 1e-3, 1.8e-2),
+    # ViT-B/16 geometry (BASELINE.json configs[2], the headline): 12 heads, D 768, M 3072, 197 tokens; 2 of its 12 layers
+    "vit_b_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=13), 2,
+                    1.2e-2, 8e-3, 1.8e-2),
+    # ViT-L/16 geometry (BASELINE.json configs[3]): 16 heads, D 1024, M 4096, 197 tokens; 2 of its 24 layers
+    "vit_l_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=11), 2,
+                    1.0e-2, 8e-3, 1.6e-2),
+}
+
+
+def _vt_setup(cfg, B, dev):
     from noise_robust_vit_amd import VisionTransformer
     from oracle import vit_oracle as V
-    from oracle.simple_vit_oracle import cross_entropy_ls
     sd = V.vit_init_state_dict(seed=3, **cfg)
     # non-trivial biases / class token so that every epilogue operand is exercised
     g = torch.Generator().manual_seed(5)
@@ -138,31 +155,70 @@ def test_vision_transformer_against_oracle(dev, cfg):
     model = VisionTransformer(**cfg)
     model.load_state_dict(sd)
     model = model.to(dev).train()
-    B = 5 if cfg["hidden_dim"] < 1024 else 2
     x = torch.randn(B, 3, cfg["image_size"], cfg["image_size"], generator=g)
     y = torch.randint(0, cfg["num_classes"], (B,), generator=g)
+    return model, sd, x, y
+
+
+@pytest.mark.parametrize("case", sorted(VT_CASES))
+def test_vision_transformer_against_oracle(dev, case):
+    """torchvision-style VisionTransformer (class token, learned positions, biased in/out projections, final LN): logits,
+    loss and EVERY parameter gradient against the CPU oracle.  Parity unpinned by the reference (its forward cannot run,
+    SURVEY.md §0): the oracle is pinned against torch.nn.MultiheadAttention in tests/test_oracle_vit.py."""
+    from oracle import vit_oracle as V
+    from oracle.simple_vit_oracle import cross_entropy_ls
+    cfg, B, tol_ref, tol_emu, tol_grad = VT_CASES[case]
+    model, sd, x, y = _vt_setup(cfg, B, dev)
     logits = model(x.to(dev))
     loss = torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.1)
     loss.backward()
+    torch.set_num_threads(8)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref = V.vit_forward(leaves, x, patch_size=cfg["patch_size"], num_heads=cfg["num_heads"])
     ref_loss = cross_entropy_ls(ref, y)
     ref_loss.backward()
     emu = V.vit_forward(sd, x, patch_size=cfg["patch_size"], num_heads=cfg["num_heads"], emulate_bf16=True)
-    e_ref, e_emu = relmax(logits, ref), relmax(logits, emu)
-    print(f"VT {cfg['hidden_dim']}: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}")
-    # class-token read-out (no mean pooling to average rounding-boundary flips): 3e-3 against the emulation for the small
-    # geometries; at 197 tokens x 2 layers the flips alone give 2e-3 .. 5e-3 (measured over five geometries: the kernels are
-    # always closer to the emulating oracle than the emulating oracle is to the fp32 one), hence 8e-3 for the ViT-L case
-    emu_tol = 3 * LOGIT_TOL_EMULATED if cfg["image_size"] < 224 else 8e-3
-    assert e_ref < LOGIT_TOL_FP32REF and e_emu < emu_tol
-    assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
+    e_ref, e_emu, e_oo = relmax(logits, ref), relmax(logits, emu), relmax(emu, ref)
     ref_grads = {k: v.grad for k, v in leaves.items()}
-    print("worst grad:", check_grads(model, ref_grads))
+    worst = check_grads(model, ref_grads, tol=tol_grad)
+    print(f"VT {case}: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e} (emulating vs fp32 oracle {e_oo:.3e}), "
+          f"loss {loss.item():.6f} vs {ref_loss.item():.6f}, worst grad rel-L2 {worst[0]:.3e} ({worst[1]})")
+    assert e_ref < tol_ref and e_emu < tol_emu
+    assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
+
+
+@pytest.mark.parametrize("case", ["d192_l2_n5", "vit_b_16_l2"])
+def test_vision_transformer_stage_localisation(dev, case):
+    """Where do kernel and bf16-emulating oracle part ways?  Per stage (patch embedding, every attention / MLP half):
+    the accumulated difference and the ISOLATED difference (the HIP half applied to the emulating oracle's own input of
+    that stage).  A rounding point the emulation misses, or a wrong kernel, is one stage with a large isolated error;
+    rounding-boundary flips give every stage the same small one.  The table is printed and, on the GPU box, written to
+    gpurun_out/ (profiles/r02_vt_stage_parity.txt is a committed copy)."""
+    import os
+    from parity_tools import format_table, vt_stage_table
+    cfg, B, _, _, _ = VT_CASES[case]
+    model, sd, x, _ = _vt_setup(cfg, B, dev)
+    rows = vt_stage_table(model, sd, x, patch_size=cfg["patch_size"], num_heads=cfg["num_heads"], dev=dev)
+    text = format_table(f"VisionTransformer {case} (batch {B}): max-norm relative differences of the residual stream", rows)
+    print("\n" + text)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, f"vt_stage_parity_{case}.txt"), "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+    iso = [r[3] for r in rows]
+    # isolated: one half on identical inputs differs from the emulation only by fp32 summation order and the bf16
+    # rounding-boundary flips that order causes: every stage stays under 1e-3 (north-star tolerance), and no stage
+    # stands out (a missed rounding point would be an outlier by an order of magnitude)
+    assert max(iso) < 1e-3, text
+    assert max(iso) < 20 * (sorted(iso)[len(iso) // 2] + 1e-7), text
 
 
 def test_simplevit_s16_depth12_against_oracle(dev):
-    """ViT-S/16 geometry (BASELINE.json configs[1]) at batch 2: 12 layers of accumulated bf16 rounding."""
+    """ViT-S/16 geometry (BASELINE.json configs[1]) at batch 2: 12 layers of accumulated bf16 rounding, logits, loss and
+    every parameter gradient."""
     from noise_robust_vit_amd import SimpleViT
     from oracle import simple_vit_oracle as O
     torch.manual_seed(0)
@@ -170,14 +226,85 @@ def test_simplevit_s16_depth12_against_oracle(dev):
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 3, 224, 224, generator=g)
-    logits = model.to(dev)(x.to(dev))
+    y = torch.randint(0, 1000, (2,), generator=g)
+    model = model.to(dev).train()
+    logits = model(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.1)
+    loss.backward()
     torch.set_num_threads(8)
-    ref = O.simple_vit_forward(sd, x, patch_size=16, heads=6)
+    ref, ref_loss, ref_grads = O.simple_vit_loss_and_grads(sd, x, y, patch_size=16, heads=6)
     emu = O.simple_vit_forward(sd, x, patch_size=16, heads=6, emulate_bf16=True)
     e_ref, e_emu = relmax(logits, ref), relmax(logits, emu)
-    print(f"SimpleViT-S/16 depth 12: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}")
+    worst = check_grads(model, ref_grads, tol=2e-2)
+    print(f"SimpleViT-S/16 depth 12: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}, "
+          f"loss {loss.item():.6f} vs {ref_loss.item():.6f}, worst grad rel-L2 {worst[0]:.3e} ({worst[1]})")
     assert e_ref < LOGIT_TOL_FP32REF
-    assert e_emu < 3 * LOGIT_TOL_EMULATED      # 12 layers: rounding-boundary flips accumulate
+    assert e_emu < LOGIT_TOL_EMULATED            # measured 3.1e-4: mean pooling averages the rounding-boundary flips
+    assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
+
+
+def test_simplevit_other_input_size_than_constructed(dev):
+    """The reference rebuilds the sincos table from the actual patch grid on every forward (simple_vit.py:141-143), so a
+    SimpleViT accepts any image size divisible by the patch: here a model constructed for 32 x 32 runs 64 x 48 (a 4 x 3
+    grid, non-square) and must match the oracle; the table is NOT read past its end."""
+    from noise_robust_vit_amd import SimpleViT
+    from oracle import simple_vit_oracle as O
+    torch.manual_seed(0)
+    model = SimpleViT(image_size=32, patch_size=16, num_classes=10, dim=128, depth=1, heads=2, mlp_dim=256)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(3)
+    for hw in ((64, 48), (32, 32), (16, 80)):
+        x = torch.randn(3, 3, *hw, generator=g)
+        logits = model(x.to(dev))
+        emu = O.simple_vit_forward(sd, x, patch_size=16, heads=2, emulate_bf16=True)
+        assert relmax(logits, emu) < LOGIT_TOL_EMULATED, (hw, relmax(logits, emu))
+
+
+def test_lucid_vit_rejects_other_input_size(dev):
+    """lucidrains-style ViT has a learned [1, n + 1, D] table: another grid is a shape error in the reference
+    (learnable_memory_vit.py: x += self.pos_embedding[:, :(n + 1)] cannot broadcast) and must be one here, not an
+    out-of-bounds read of the table."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd._lib import NrvError
+    vit = ViT(image_size=32, patch_size=16, num_classes=5, dim=64, depth=1, heads=1, mlp_dim=128).to(dev)
+    with pytest.raises((NrvError, RuntimeError)):
+        vit(torch.randn(2, 3, 64, 64, device=dev))
+
+
+@pytest.mark.parametrize("batch_first", [True, False])
+def test_multihead_attention_forward_matches_torch_module(dev, batch_first):
+    """`MultiheadAttention.forward(x, x, x, need_weights=False) -> (out, None)` (reference: the forked module at
+    utils.py:650-751, whose own forward raises upstream) against installed torch.nn.MultiheadAttention with the same
+    packed parameters: output and every gradient, on the CPU in fp32."""
+    from noise_robust_vit_amd.vit import MultiheadAttention
+    torch.manual_seed(0)
+    E, H, B, S = 192, 3, 4, 37
+    mine = MultiheadAttention(E, H, batch_first=batch_first)
+    with torch.no_grad():
+        mine.in_proj_bias.normal_(std=0.1); mine.out_proj.bias.normal_(std=0.1)
+    ref = torch.nn.MultiheadAttention(E, H, batch_first=batch_first)
+    ref.load_state_dict({k: v.detach().clone() for k, v in mine.state_dict().items()})
+    x = torch.randn(B, S, E) if batch_first else torch.randn(S, B, E)
+    w = torch.randn_like(x)
+    xr = x.clone().requires_grad_(True)
+    out_r, _ = ref(xr, xr, xr, need_weights=False)
+    (out_r * w).sum().backward()
+    mine = mine.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out, attn_w = mine(xd, xd, xd, need_weights=False)
+    assert attn_w is None and out.shape == x.shape
+    (out * w.to(dev)).sum().backward()
+    e = relmax(out, out_r)
+    print(f"MultiheadAttention.forward batch_first={batch_first}: {e:.3e} vs torch.nn.MultiheadAttention (fp32)")
+    assert e < BRANCH_TOL_FP32REF
+    pairs = [(xd.grad, xr.grad, "x")] + [(p.grad, dict(ref.named_parameters())[n].grad, n) for n, p in mine.named_parameters()]
+    for g, r, name in pairs:
+        g = g.detach().float().cpu().reshape(-1); r = r.reshape(-1)
+        rel = ((g - r).norm() / r.norm()).item()
+        assert rel < 2e-2, (name, rel)
+    with pytest.raises(NotImplementedError):
+        mine(xd, xd, xd, need_weights=True)
 
 
 def test_state_dict_roundtrip_and_legacy_mlp_keys(dev):
@@ -283,3 +410,98 @@ def test_training_actually_learns(dev):
     with torch.no_grad():
         acc = (vit(x).argmax(-1) == y).float().mean().item()
     assert acc > 0.9, acc
+
+
+def test_mae_vit_b_geometry_49_tokens_against_oracle(dev):
+    """BASELINE.json configs[4] at its real geometry: ViT-B/16 encoder width (D 768, 12 heads, M 3072) on the 49 kept of 196
+    tokens (2 of its 12 layers), the wrapper's 512-wide decoder on all 196; loss and every gradient against the CPU
+    oracle (oracle/mae_oracle.py, itself pinned by the reference-generated fixture above)."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd.mae import MAE
+    from oracle import mae_oracle as MO
+    torch.manual_seed(0)
+    enc = ViT(image_size=224, patch_size=16, num_classes=10, dim=768, depth=2, heads=12, mlp_dim=3072)
+    mae = MAE(encoder=enc, decoder_dim=512, masking_ratio=0.75, decoder_depth=1, decoder_heads=8, decoder_dim_head=64)
+    with torch.no_grad():                                  # the reference initialises these N(0, 1): keep the tokens O(1)
+        enc.pos_embedding.mul_(0.02); enc.cls_token.mul_(0.02)
+    sd = {k: v.detach().clone() for k, v in mae.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    idx = torch.rand(2, 196, generator=g).argsort(dim=-1)
+    mae = mae.to(dev).train()
+    loss = mae(img.to(dev), rand_indices=idx.to(dev))
+    loss.backward()
+    torch.set_num_threads(8)
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref = MO.mae_forward(leaves, img, idx, patch_size=16, enc_heads=12, dec_heads=8)
+    ref.backward()
+    print(f"MAE ViT-B geometry: loss {loss.item():.6f} vs oracle {ref.item():.6f}")
+    assert abs(loss.item() - ref.item()) < 2e-3 * abs(ref.item())
+    worst = (0.0, None)
+    for k, p in mae.named_parameters():
+        r = leaves[k].grad
+        if r is None:                                       # cls_token / mlp_head are not on the MAE path (mae.py:84)
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
+        gk = p.grad.detach().float().cpu().reshape(-1); r = r.reshape(-1)
+        rel = ((gk - r).norm() / r.norm().clamp_min(1e-30)).item()
+        worst = max(worst, (rel, k))
+        assert rel < 2e-2, (k, rel)
+    print("worst grad rel-L2:", worst)
+
+
+def test_lucid_fused_qkv_images_are_cached_and_follow_updates(dev):
+    """lucid_vit.Attention feeds the fused QKV GEMM from a persistent [to_q; to_kv] buffer: no cast_transpose per forward
+    once staged, and an in-place parameter update (version bump) or a raw-pointer update (FusedAdamW -> refresh_all) is
+    picked up."""
+    from noise_robust_vit_amd import encoder, kernels
+    from noise_robust_vit_amd.lucid_vit import Attention
+    torch.manual_seed(0)
+    att = Attention(128, heads=2, dim_head=64).to(dev)
+    x = torch.randn(2, 9, 128, device=dev)
+    calls = []
+    orig = kernels.cast_transpose
+    kernels.cast_transpose = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y0 = att(x)
+            n0 = len(calls)
+            y1 = att(x)
+            assert len(calls) == n0 and torch.equal(y0, y1)          # second forward: every bf16 image comes from the cache
+            att.to_q.weight.mul_(2.0)                                 # version bump -> fused buffer and image rebuilt
+            y2 = att(x)
+            assert len(calls) > n0 and not torch.equal(y2, y0)
+            att.to_kv.weight.data.view(-1)[:] = att.to_kv.weight.data.view(-1) * 0.5     # raw update: no version bump of the Parameter
+            encoder.WEIGHTS.refresh_all()
+            y3 = att(x)
+            assert not torch.equal(y3, y2)
+    finally:
+        kernels.cast_transpose = orig
+    # gradients still reach the two source parameters
+    att.zero_grad()
+    att(x).sum().backward()
+    assert att.to_q.weight.grad is not None and att.to_kv.weight.grad is not None
+    assert att.to_q.weight.grad.shape == att.to_q.weight.shape
+
+
+def test_noisy_input_training(dev):
+    """`noise_std > 0` (the repo's namesake noisy-input training, examples/nowak.py:152-159: x + N(0, sigma^2) in front of
+    the model): the perturbation reaches the model (first-step loss differs from the clean run with the same weights) and
+    the HIP path still fits the batch through it."""
+    from noise_robust_vit_amd import SimpleViT
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(32, 3, 32, 32, generator=g).to(dev)
+    y = torch.randint(0, 10, (32,), generator=g).to(dev)
+    first = {}
+    for std in (0.0, 0.5):
+        torch.manual_seed(0)
+        vit = SimpleViT(image_size=32, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256).to(dev).train()
+        tr = Trainer(vit, TrainConfig(lr=2e-3, weight_decay=0.05, grad_max_norm=5.0, label_smoothing=0.0, noise_std=std))
+        torch.manual_seed(123)                                        # the noise stream
+        first[std] = tr.step(x, y).item()
+        if std > 0:
+            for _ in range(80):
+                last = tr.step(x, y).item()
+    assert abs(first[0.0] - first[0.5]) > 1e-4, first
+    assert last < 0.5 * first[0.5], (first, last)

@@ -121,3 +121,91 @@ def test_two_rank_gloo_matches_single_process(bucket_mib):
     if bucket_mib < 1:
         assert len(buckets) > 1
     assert sum(buckets) >= 4 * sum(p.numel() for p in Net().parameters())
+
+
+def _worker_sync_eval(rank, world, port, q):
+    """Per-rank seeds: replicas must still start from rank 0's weights (broadcast at construction, DDP semantics), and the
+    evaluation accuracy is summed onto rank 0 with one scalar reduce (examples/CIFAR100.py:148-163)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noise_robust_vit_amd.parallel import GradReducer
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    net = Net()
+    torch.manual_seed(1000 + rank)                      # replicas differ ...
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(torch.randn_like(p) * 0.5)
+    red = GradReducer(net, world)                       # ... until the reducer broadcasts rank 0's parameters
+    tr = Trainer(net, TrainConfig(lr=1e-2, grad_max_norm=5.0), red)
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(8, 16, generator=g); Y = torch.randint(0, 5, (8,), generator=g)
+    per = 8 // world
+    xs, ys = X[rank * per:(rank + 1) * per], Y[rank * per:(rank + 1) * per]
+    for _ in range(2):
+        tr.step(xs, ys)
+    w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    gathered = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    own = net(xs).argmax(1).eq(ys).float().mean().item()
+    accs = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(accs, torch.tensor([own]))
+    acc = tr.eval_step(xs, ys)
+    mean_acc = tr.evaluate([(xs, ys)])
+    if rank == 0:
+        q.put((max((gathered[0] - t).abs().max().item() for t in gathered), acc.item(), sum(a.item() for a in accs), mean_acc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_param_broadcast_and_eval_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sync_eval, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    spread, acc0, acc_sum, mean_acc = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert spread == 0.0, spread                        # identical replicas after two steps despite per-rank seeds
+    assert abs(acc0 - acc_sum) < 1e-6                   # rank 0 holds the SUM of the per-rank accuracies (dist.reduce, dst 0)
+    assert abs(mean_acc - acc_sum / 2) < 1e-6
+
+
+def _worker_forced(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from noise_robust_vit_amd.parallel import GradReducer
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 16, generator=g); Y = torch.randint(0, 5, (8,), generator=g)
+    net = Net()
+    red = GradReducer(net, 1, bucket_mib=0.001, force_collectives=True)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), orig(*a, **k))[1]
+    tr = Trainer(net, TrainConfig(lr=1e-2, grad_max_norm=5.0), red)
+    for _ in range(3):
+        tr.step(X, Y)
+    out = {k: v.detach().clone().numpy() for k, v in net.state_dict().items()}
+    q.put((out, len(calls), len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_world_one_equal_plain_run():
+    """world_size 1 with force_collectives: every bucket issues its all_reduce (the code path of the multi-GPU step) and
+    the training trajectory equals the run without a process group bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_forced, args=(_free_port(), q))
+    p.start()
+    out, ncalls, nbuckets = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert nbuckets > 1 and ncalls == 3 * nbuckets
+    ref_out, _ = _reference()
+    for k in ref_out:
+        assert torch.equal(torch.from_numpy(out[k]), ref_out[k]), k

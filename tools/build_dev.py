@@ -2,6 +2,7 @@
 """Build a developer variant of the HIP library into tools/_build/ (never loaded by the package or the tests).
 
     python tools/build_dev.py NAME [-DNRV_DEV_STAMPS] [-DNRV_X=1 ...]   ->  tools/_build/libnrv_hip_NAME.so
+    python tools/build_dev.py NAME --rev GITREV                         ->  the sources of an earlier commit (A/B baseline)
 
 Used for same-process A/B runs (tools/_devlib.use_library) and for the phase-stamp instrumentation of the NT GEMM
 (-DNRV_DEV_STAMPS adds `nrv_dev_read_stamps`).  hipcc cross-compiles: build here, the .so travels to the GPU box."""
@@ -11,8 +12,27 @@ sys.path.insert(0, ROOT)
 from noise_robust_vit_amd import build as B
 
 if __name__ == "__main__":
+    import subprocess
     name = sys.argv[1]
-    flags = tuple(a for a in sys.argv[2:] if a.startswith("-"))
+    args = sys.argv[2:]
     out = os.path.join(ROOT, "tools", "_build")
+    csrc, sources = B.CSRC, None
+    if "--rev" in args:
+        rev = args[args.index("--rev") + 1]
+        args = [a for a in args if a not in ("--rev", rev)]
+        csrc = os.path.join(out, f"src_{name}")
+        os.makedirs(csrc, exist_ok=True)
+        listing = subprocess.run(["git", "ls-tree", "--name-only", rev, "noise_robust_vit_amd/csrc/"], cwd=ROOT,
+                                 capture_output=True, text=True, check=True).stdout.split()
+        sources = []
+        for f in listing:
+            base = os.path.basename(f)
+            text = subprocess.run(["git", "show", f"{rev}:{f}"], cwd=ROOT, capture_output=True, text=True, check=True).stdout
+            dst = os.path.join(csrc, base)
+            if not os.path.exists(dst) or open(dst).read() != text:
+                open(dst, "w").write(text)
+            if base.endswith(".hip"):
+                sources.append(base)
+    flags = tuple(a for a in args if a.startswith("-"))
     B.build(force=False, verbose=True, lib=os.path.join(out, f"libnrv_hip_{name}.so"),
-            objdir=os.path.join(out, f"obj_{name}"), extra_flags=flags)
+            objdir=os.path.join(out, f"obj_{name}"), extra_flags=flags, csrc=csrc, sources=sources)
