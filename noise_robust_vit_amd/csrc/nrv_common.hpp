@@ -139,6 +139,22 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_bas
         : "memory");
 }
 
+// the same with a scalar byte offset added by the memory unit (soffset): a K loop advances the SCALAR and keeps the per-lane
+// offset constant, so a DMA costs no vector-ALU instruction (the range check subtracts soffset from the record count)
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset, unsigned soffset) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_base));
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc), "s"(lds_addr), "s"(soffset)
+        : "memory");
+}
+
 __device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {
     return *reinterpret_cast<const bf16x8_t*>(p);
 }

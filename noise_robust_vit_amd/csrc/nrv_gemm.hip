@@ -441,17 +441,24 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         st_b[i] = (n0 + r < N) ? (unsigned)((long long)r * p.ldb * 2) + c * 16 : NRV_OOB;
     }
-    // one DMA instruction (index d of the CA + CB that make up a K-tile) of tile kt into stage buffer buf
+    // one DMA instruction (index d of the CA + CB that make up a K-tile) of tile kt into stage buffer buf.  The per-lane
+    // offset is a constant of the tile (row, swizzled chunk; NRV_OOB for rows beyond the matrix), the K position is the
+    // scalar soffset: no vector instruction per DMA.  Only a K that is not a multiple of 64 needs a per-lane test, in
+    // its last tile (chunks at k >= K must read zero, and they are not at the end of the buffer).
+    const int nk = (K + BK - 1) / BK;
+    const bool ktail = (K & (BK - 1)) != 0;
     auto dma_one = [&](int buf, int kt, int d) {
         char* base = smem + buf * C::STAGE;
         const int k0 = kt * BK;
         const bool isA = d < C::CA;
         const int i = isA ? d : d - C::CA;
-        const int r = (i * C::NWAVES + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const unsigned so = isA ? st_a[isA ? i : 0] : st_b[isA ? 0 : i];
-        const bool ok = (k0 + c * 8 < K) && so != NRV_OOB;
-        dma16(isA ? ra : rb, base + (isA ? 0 : C::A_BYTES) + (i * C::NWAVES + wave) * 1024, ok ? so + k0 * 2 : NRV_OOB);
+        unsigned vo = isA ? st_a[isA ? i : 0] : st_b[isA ? 0 : i];
+        if (ktail && kt == nk - 1) {
+            const int r = (i * C::NWAVES + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            vo = (k0 + c * 8 < K) ? vo : NRV_OOB;
+        }
+        dma16s(isA ? ra : rb, base + (isA ? 0 : C::A_BYTES) + (i * C::NWAVES + wave) * 1024, vo, (unsigned)(k0 * 2));
     };
     constexpr int ND = C::CA + C::CB;            // DMA instructions per thread per K-tile
     constexpr int NG = C::MI;                    // MFMA groups per K-tile: 2 k-steps x MI/2 row pairs
@@ -469,7 +476,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (K + BK - 1) / BK;
 #ifdef NRV_DEV_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (p.stamps) t0 = __builtin_amdgcn_s_memrealtime();
@@ -563,11 +569,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     const long long arow0 = remap_row(t_begin, p.a_group, p.a_group_stride, p.a_row_offset);
     const bf16_t* abase = p.A + arow0 * p.lda + m0;
     const bf16_t* bbase = p.B + (long long)t_begin * p.ldb + n0;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, 0x7fffffffull);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(bbase, 0x7fffffffull);
+    const int trem = t_end - t_begin;                       // token rows of this split (<= 0: nothing to do)
+    const int acols = M - m0 < BM ? M - m0 : BM, bcols = N - n0 < BN ? N - n0 : BN;
+    // plain case: the records end with the last valid column of the last token row of the split, so rows >= t_end read as
+    // zero through the range check and a DMA costs no vector instruction (per-lane offset constant, K position = soffset).
+    // row-remapped A (class-token slot of the patch embedding): per-DMA address arithmetic, window of 2 GiB.
+    const bool a_remap = p.a_group > 0;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (a_remap || trem <= 0) ? 0x7fffffffull : ((unsigned long long)(trem - 1) * p.lda + acols) * 2ull);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(bbase, trem <= 0 ? 0ull : ((unsigned long long)(trem - 1) * p.ldb + bcols) * 2ull);
 
     // staging: DMA instruction i of this wave fills token rows 2*(8 i + wave), +1 of a tile
     int st_r[4], st_col[4];
+    unsigned va0[4], vb0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int R = 2 * (i * 8 + wave) + (lane >> 5);
@@ -575,22 +588,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
         const int ul = (ch >> 1) ^ (R & 7);
         st_r[i] = R;
         st_col[i] = (ul * 2 + (ch & 1)) * 8;
+        va0[i] = st_col[i] < acols ? (unsigned)(((long long)R * p.lda + st_col[i]) * 2) : NRV_OOB;
+        vb0[i] = st_col[i] < bcols ? (unsigned)(((long long)R * p.ldb + st_col[i]) * 2) : NRV_OOB;
     }
+    const unsigned a_step = (unsigned)(BK * p.lda * 2), b_step = (unsigned)(BK * p.ldb * 2);
 
     // one DMA instruction d (0..3: A rows, 4..7: B rows) of K-tile kt into stage buffer buf
     auto dma_one = [&](int buf, int kt, int d) {
         char* base = smem + buf * STAGE_BYTES;
         const bool isA = d < 4;
         const int i = d & 3;
-        const int t = t_begin + kt * BK + st_r[i];
-        const bool tok = t < t_end;
         if (isA) {
-            const long long ar = remap_row(t, p.a_group, p.a_group_stride, p.a_row_offset) - arow0;
-            const unsigned va = (tok && (m0 + st_col[i] < M)) ? (unsigned)((ar * p.lda + st_col[i]) * 2) : NRV_OOB;
-            dma16(ra, base + (i * 8 + wave) * 1024, va);
+            if (a_remap) {
+                const int t = t_begin + kt * BK + st_r[i];
+                const long long ar = remap_row(t, p.a_group, p.a_group_stride, p.a_row_offset) - arow0;
+                const unsigned va = (t < t_end && st_col[i] < acols) ? (unsigned)((ar * p.lda + st_col[i]) * 2) : NRV_OOB;
+                dma16(ra, base + (i * 8 + wave) * 1024, va);
+            } else {
+                dma16s(ra, base + (i * 8 + wave) * 1024, va0[i], (unsigned)kt * a_step);
+            }
         } else {
-            const unsigned vb = (tok && (n0 + st_col[i] < N)) ? (unsigned)(((long long)(t - t_begin) * p.ldb + st_col[i]) * 2) : NRV_OOB;
-            dma16(rb, base + B_TILE_OFF + (i * 8 + wave) * 1024, vb);
+            dma16s(rb, base + B_TILE_OFF + (i * 8 + wave) * 1024, vb0[i], (unsigned)kt * b_step);
         }
     };
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL_FP32REF = 6e-3      # SimpleViT, bf16 operands vs fp32 reference, max-norm relative (measured 6.4e-4 ... 2.9e-3)
 LOGIT_TOL_EMULATED = 1e-3     # same rounding points as the kernels (north-star tolerance; measured 4.8e-6 ... 6.9e-4)
-LOSS_TOL_FP32REF = 2e-3       # measured <= 2.7e-4 ... 9e-4
+LOSS_TOL_FP32REF = 3e-3       # measured 5e-6 ... 1.6e-3 (ViT-B geometry)
 GRAD_RELL2_TOL = 1e-2         # per-parameter relative L2 vs fp32 autograd of the oracle (measured worst 4.4e-3)
 GRAD_COS_TOL = 0.999
 BRANCH_TOL_FP32REF = 1.2e-2   # a single half's OUTPUT (no residual stream to dilute it) vs fp32: bf16 operands, measured <= 6e-3
@@ -131,15 +131,15 @@ VT_CASES = {
     # Bounds are <= 2x the values measured on MI355X (DESIGN.md "Numerics" lists the measurements); the north-star 1e-3
     # is met against the emulating oracle only where mean pooling or many tokens average the rounding-boundary flips.
     "d192_l2_n5": (dict(image_size=32, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10), 5,
-                   1.2e-2, 3e-3, 1.8e-2),
+                   1.2e-2, 3e-3, 1.8e-2),          # measured 5.9e-3, 1.5e-3, 9.0e-3
     "d128_l1_n17": (dict(image_size=64, patch_size=16, num_layers=1, num_heads=2, hidden_dim=128, mlp_dim=256, num_classes=7), 5,
-                    1.1e-2, 1e-3, 1.8e-2),
+                    1.1e-2, 1e-3, 1.6e-2),         # measured 5.2e-3, 3.6e-7, 7.9e-3
     # ViT-B/16 geometry (BASELINE.json configs[2], the headline): 12 heads, D 768, M 3072, 197 tokens; 2 of its 12 layers
     "vit_b_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=13), 2,
-                    1.2e-2, 8e-3, 1.8e-2),
+                    1.0e-2, 6.5e-3, 1.6e-2),       # measured 4.9e-3, 3.2e-3, 8.0e-3
     # ViT-L/16 geometry (BASELINE.json configs[3]): 16 heads, D 1024, M 4096, 197 tokens; 2 of its 24 layers
     "vit_l_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=11), 2,
-                    1.0e-2, 8e-3, 1.6e-2),
+                    1.0e-2, 1.1e-2, 1.6e-2),       # measured 4.7e-3, 5.5e-3 (the emulating oracle itself is 4.7e-3 from the fp32 one), 7.9e-3
 }
 
 
@@ -208,12 +208,14 @@ def test_vision_transformer_stage_localisation(dev, case):
             f.write(text + "\n")
     except OSError:
         pass
-    iso = [r[3] for r in rows]
-    # isolated: one half on identical inputs differs from the emulation only by fp32 summation order and the bf16
-    # rounding-boundary flips that order causes: every stage stays under 1e-3 (north-star tolerance), and no stage
-    # stands out (a missed rounding point would be an outlier by an order of magnitude)
-    assert max(iso) < 1e-3, text
-    assert max(iso) < 20 * (sorted(iso)[len(iso) // 2] + 1e-7), text
+    iso = sorted(r[3] for r in rows)
+    # Isolated, a half on identical inputs equals the emulation to fp32 rounding (~1e-7) -- unless one of its bf16 stores
+    # lands on a rounding boundary and flips (fp32 summation order differs), which shows as ~1e-4 on that stage only.
+    # A rounding point missed by the emulation (or a wrong kernel) would make EVERY stage of that kind large: so the
+    # median must be at fp32-rounding level and no stage may exceed the north-star 1e-3.
+    assert iso[-1] < 1e-3, text
+    if cfg["image_size"] < 224:      # 5 tokens: most stages see no flip at all (at 197 tokens x D 768 every stage has a few hundred)
+        assert iso[len(iso) // 2] < 1e-5, text
 
 
 def test_simplevit_s16_depth12_against_oracle(dev):
@@ -235,7 +237,7 @@ def test_simplevit_s16_depth12_against_oracle(dev):
     ref, ref_loss, ref_grads = O.simple_vit_loss_and_grads(sd, x, y, patch_size=16, heads=6)
     emu = O.simple_vit_forward(sd, x, patch_size=16, heads=6, emulate_bf16=True)
     e_ref, e_emu = relmax(logits, ref), relmax(logits, emu)
-    worst = check_grads(model, ref_grads, tol=2e-2)
+    worst = check_grads(model, ref_grads)          # measured 4.9e-3
     print(f"SimpleViT-S/16 depth 12: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}, "
           f"loss {loss.item():.6f} vs {ref_loss.item():.6f}, worst grad rel-L2 {worst[0]:.3e} ({worst[1]})")
     assert e_ref < LOGIT_TOL_FP32REF
@@ -446,7 +448,7 @@ def test_mae_vit_b_geometry_49_tokens_against_oracle(dev):
         gk = p.grad.detach().float().cpu().reshape(-1); r = r.reshape(-1)
         rel = ((gk - r).norm() / r.norm().clamp_min(1e-30)).item()
         worst = max(worst, (rel, k))
-        assert rel < 2e-2, (k, rel)
+        assert rel < 1.8e-2, (k, rel)                    # measured worst 8.7e-3
     print("worst grad rel-L2:", worst)
 
 
