@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 6
+#define NRV_ABI_VERSION 7
 
 /* dtype codes */
 #define NRV_F32 0
@@ -91,7 +91,11 @@ int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const flo
  *        NRV_EPI_DGELU epilogue is then one multiply, no second erf/exp evaluation.
  *   Output row remap (class-token slot, vit.py:341-342): if out_group > 0 the result row m is
  *   stored at row (m / out_group) * out_group_stride + (m % out_group) + out_row_offset of C
- *   (and of aux, when aux_row_mod == 0).
+ *   (and of aux, when aux_row_mod == 0).  The remap and aux_row_mod ride on NRV_EPI_BIAS_RESIDUAL (the patch
+ *   embedding: bias + positional table, optionally with the class-token slot); with any other epilogue
+ *   they are refused (NRV_ERR_EPILOGUE).
+ *   Rows >= M and columns >= N of a tile are never written; ldc, ld_aux * 1280 bytes must stay below 2^31
+ *   (a wave addresses its 160-row block with 32-bit offsets).
  * ---------------------------------------------------------------------------------------- */
 int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
                      void* C, int c_dtype, int64_t ldc,

@@ -18,7 +18,7 @@ LIB_PATH = _DEFAULT_LIB       # no environment override: what runs is the in-tre
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {

@@ -477,16 +477,25 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
         for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #ifdef NRV_DEV_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, wait_vm = 0, wait_bar = 0, loop_c0 = 0;
     if (p.stamps) t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
     for (int d = 0; d < ND; ++d) dma_one(0, 0, d);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
+#ifdef NRV_DEV_STAMPS
+        const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NRV_DEV_STAMPS
+        const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
 #ifdef NRV_DEV_STAMPS
+        const unsigned long long w2 = __builtin_amdgcn_s_memtime();
+        if (kt > 0) { wait_vm += w1 - w0; wait_bar += w2 - w1; }
+        if (kt == 1) loop_c0 = w0;
         if (p.stamps && kt == 0) t1 = __builtin_amdgcn_s_memrealtime();
 #endif
         const bool more = kt + 1 < nk;
@@ -526,6 +535,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
     __syncthreads();     // every wave is done with the tile buffers: reuse them as epilogue patches
 #ifdef NRV_DEV_STAMPS
     if (p.stamps) t2 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long loop_c1 = __builtin_amdgcn_s_memtime();
 #endif
     if (REMAP) epilogue_remap<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
     else epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
@@ -537,6 +547,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
             unsigned long long* o = p.stamps + (unsigned long long)blockIdx.x * 5;
             o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_memrealtime();
             o[4] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4 /* HW_REG_HW_ID */) | ((unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20 /* XCC_ID */) << 32);
+        }
+        if (lane == 0) {        // per wave, K-tiles 1 .. nk-1: shader cycles parked on vmcnt(0), on the barrier, and in total
+            unsigned long long* w = p.stamps + (1u << 19) + ((unsigned long long)blockIdx.x * C::NWAVES + wave) * 3;
+            w[0] = wait_vm; w[1] = wait_bar; w[2] = loop_c1 - loop_c0;
         }
     }
 #endif
@@ -794,8 +808,7 @@ template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
     const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
     if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
-        return tc >= 320 ? launch_nt_cfg<Cfg320, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s)
-                         : launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);
+        return launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);    // one launch per step: 256-row tiles only
     if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 192) return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32, false>(p, s);
