@@ -28,6 +28,9 @@ using namespace nrv_attn;
 constexpr int SK_THREADS = 1024;      // 16 waves: one 16-query tile each (N <= 256)
 constexpr int SK_WAVES = 16;
 constexpr int SKB_THREADS = 512;      // key-owner backward kernel
+#ifndef NRV_SK_TPW
+#define NRV_SK_TPW 2
+#endif
 
 struct SinkParams {
     const bf16_t* qkv;     // [B, N, 3*H*64]
@@ -193,16 +196,27 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_fwd_kernel(const SinkPara
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, query-owner kernel: dQ, and dS^T / P7^T scratch for the key-owner kernel
+// backward, query-owner kernel: dQ, and dS^T / P7^T scratch for the key-owner kernel.
+// 8 FAT waves (2 per SIMD, <= 256 VGPRs), each owning TWO 16-query tiles (wave w: tiles w and w + 8): a tile's state is
+// G (fp32, NP / 4 registers) + P0 (packed bf16, NP / 8) and it lives through seven normalisation steps.  The round-1 form
+// (16 waves x one tile = 4 waves per SIMD, 128 VGPRs) spilled 488 registers to scratch at N = 197 and took 3.5 ms per
+// layer on ViT-B/16 (batch 256).  K / V row fragments are read from LDS once per key tile and feed both query tiles.
 // ---------------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(SK_THREADS) void sinkhorn_bwd_q_kernel(const SinkParams p) {
+// hipcc unrolls the key-tile loops fully (the register arrays need static indices) and then hoists every LDS vector load of
+// every iteration to the top: hundreds of live registers, spilled.  A compiler-level memory fence per iteration keeps the
+// loads where they are written (no instruction is emitted).
+#define SK_KEEP_ORDER() asm volatile("" ::: "memory")
+
+template <int NP, int TPW>          // TPW = query tiles per wave: 16 / TPW waves
+__global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_kernel(const SinkParams p) {
+    constexpr int SKQ_WAVES = 16 / TPW, SKQ_THREADS = 64 * SKQ_WAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;                                            // row + transposed reads
     char* vimg = smem + NP * 128;                                 // row reads
     float* bv = reinterpret_cast<float*>(smem + 2 * NP * 128);    // [4][NP]: b0 = 1, b1, b2, b3
     float* kap = bv + 4 * NP;                                     // [NP] column correction of the current step
-    float* colpart = kap + NP;                                    // [SK_WAVES][NP]
+    float* colpart = kap + NP;                                    // [SKQ_WAVES][NP]
+    constexpr int NT = NP / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N;
@@ -210,9 +224,9 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_bwd_q_kernel(const SinkPa
     const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
     const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
     const float* scal = p.scal + (long long)bh * 7 * N;
-    load_image<NP, false, SK_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
-    load_image<NP, false, SK_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
-    for (int j = tid; j < NP; j += SK_THREADS) {
+    load_image<NP, false, SKQ_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
+    load_image<NP, false, SKQ_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
+    for (int j = tid; j < NP; j += SKQ_THREADS) {
         bv[j] = j < N ? 1.0f : 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t) bv[(t + 1) * NP + j] = j < N ? scal[(2 * t + 1) * N + j] : 0.f;
@@ -221,159 +235,201 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_bwd_q_kernel(const SinkPa
 
     const int g = lane >> 4, qc = lane & 15;
     const int nqt = (N + 15) >> 4;
-    const bool active = wave < nqt;
-    const int q = wave * 16 + qc;
-    const bool q_ok = active && q < N;
-    const int qr = q < N ? q : N - 1;
-
-    // a0 = 1, a1..a4 of this lane's query
-    float av[5];
-    av[0] = q_ok ? 1.f : 0.f;
+    bool active[TPW], q_ok[TPW];
+    int q[TPW];
+    float av[TPW][5];                 // a0 = 1, a1 .. a4 of the lane's query, per tile
+    unsigned p0h[TPW][NP / 8];        // P0, packed bf16 pairs: element e of key tile kt in half (e & 1) of word 2 kt + (e >> 1)
+    f32x4_t G[TPW][NT];               // G = dP7^T (fp32), walked back through the normalisations in place
 #pragma unroll
-    for (int t = 0; t < 4; ++t) av[t + 1] = q_ok ? scal[(2 * t) * N + q] : 0.f;
-
-    // P0 (packed bf16 pairs: element e of tile kt in half (e & 1) of word kt*2 + (e >> 1)) and G = dP7^T (fp32)
-    unsigned p0h[NP / 8];
-    f32x4_t G[NP / 16];
-    bf16x8_t qf[2], dof[2];
+    for (int u = 0; u < TPW; ++u) {        // one tile after the other: only one tile's Q / dO fragments are live at a time
+        const int tile = wave + SKQ_WAVES * u;
+        active[u] = tile < nqt;
+        q[u] = tile * 16 + qc;
+        q_ok[u] = active[u] && q[u] < N;
+        const int qr = q[u] < N ? q[u] : N - 1;
+        av[u][0] = q_ok[u] ? 1.f : 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
-        dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
-    }
-    {
+        for (int t = 0; t < 4; ++t) av[u][t + 1] = q_ok[u] ? scal[(2 * t) * N + qr] : 0.f;
+        bf16x8_t qf[2], dof[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
+            dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
+        }
         const float lse2 = p.lse[(long long)bh * N + qr] * LOG2E;
         const float sc = p.scale * LOG2E;
 #pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt) {
+        for (int kt = 0; kt < NT; ++kt) {
+            SK_KEEP_ORDER();
             f32x4_t st = {0.f, 0.f, 0.f, 0.f};
-            G[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            G[u][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 st = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[ks], st);
-                G[kt] = mfma16(row_frag_img(vimg, kt * 16, ks, lane), dof[ks], G[kt]);
+                G[u][kt] = mfma16(row_frag_img(vimg, kt * 16, ks, lane), dof[ks], G[u][kt]);
             }
             float pv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = kt * 16 + 4 * g + e;
-                pv[e] = (key < N && q_ok) ? __builtin_amdgcn_exp2f(st[e] * sc - lse2) : 0.f;
+                pv[e] = (key < N && q_ok[u]) ? __builtin_amdgcn_exp2f(st[e] * sc - lse2) : 0.f;
             }
-            p0h[kt * 2] = pack_bf16x2(pv[0], pv[1]);
-            p0h[kt * 2 + 1] = pack_bf16x2(pv[2], pv[3]);
+            p0h[u][kt * 2] = pack_bf16x2(pv[0], pv[1]);
+            p0h[u][kt * 2 + 1] = pack_bf16x2(pv[2], pv[3]);
         }
     }
-    auto P0 = [&](int kt, int e) -> float {
-        const unsigned w = p0h[kt * 2 + (e >> 1)];
+    // unpack on every use: the empty asm makes the word opaque, otherwise hipcc keeps all 8 NT unpacked fp32 copies of P0
+    // alive next to the packed ones (the register file then overflows into scratch)
+    auto P0 = [&](int u, int kt, int e) -> float {
+        unsigned w = p0h[u][kt * 2 + (e >> 1)];
+        asm volatile("" : "+v"(w));
         return (e & 1) ? bf16hi_to_f32(w) : bf16lo_to_f32(w);
     };
 
-    // hand P7^T to the key-owner kernel before G is overwritten:  P7 = a4 P0 b3
-    bf16_t* wsp = p.ws_p + (long long)bh * NP * NP;
-    bf16_t* wsd = p.ws_ds + (long long)bh * NP * NP;
-    if (active) {
+    // hand P7^T to the key-owner kernel before G is overwritten:  P7 = a4 P0 b3.  The scratch is written through buffer
+    // descriptors: the per-lane offset (key row 4 g + e, query column) is 4 registers per tile, the key tile is the scalar
+    // soffset (with plain pointers hipcc precomputes a 64-bit address per store: ~450 registers, spilled).
+    const __amdgpu_buffer_rsrc_t rwp = make_rsrc(p.ws_p + (long long)bh * NP * NP, (unsigned long long)NP * NP * 2);
+    const __amdgpu_buffer_rsrc_t rwd = make_rsrc(p.ws_ds + (long long)bh * NP * NP, (unsigned long long)NP * NP * 2);
+    unsigned wo[TPW][4];
 #pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt) {
-            const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
+    for (int u = 0; u < TPW; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                wsp[(long long)(kt * 16 + 4 * g + e) * NP + q] = f32_to_bf16(av[4] * P0(kt, e) * b3[e]);
+        for (int e = 0; e < 4; ++e) wo[u][e] = (unsigned)(((4 * g + e) * NP + q[u]) * 2);
+    auto ws_store = [&](const __amdgpu_buffer_rsrc_t& r, int u, int kt, int e, unsigned short v) {
+        __builtin_amdgcn_raw_buffer_store_b16((short)v, r, wo[u][e], kt * 16 * NP * 2, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        if (active[u]) {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ws_store(rwp, u, kt, e, f32_to_bf16(av[u][4] * P0(u, kt, e) * b3[e]));
+                SK_KEEP_ORDER();
+            }
         }
     }
 
     // walk the normalisations backwards: steps 7 (row) 6 (col) 5 (row) 4 (col) 3 (row) 2 (col) 1 (row)
-    // (fully unrolled: av[] must be indexed statically or it lands in scratch)
+    // (fully unrolled: av[][] must be indexed statically or it lands in scratch)
 #pragma unroll
     for (int t = 3; t >= 0; --t) {
-        {   // row step with alpha = a_{t+1}, alpha_prev = a_t, beta = b_t      (a index: av[t+1], av[t]; b index t)
-            const float al = av[t + 1], alp = av[t];
+        {   // row step with alpha = a_{t+1}, alpha_prev = a_t, beta = b_t
             const float* bt = bv + t * NP;
-            float rho = 0.f;
+            float rho[TPW];
 #pragma unroll
-            for (int kt = 0; kt < NP / 16; ++kt) {
+            for (int u = 0; u < TPW; ++u) rho[u] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
                 const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bt + kt * 16 + 4 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rho += G[kt][e] * P0(kt, e) * b4[e];
-            }
-            rho += __shfl_xor(rho, 16, 64);
-            rho += __shfl_xor(rho, 32, 64);
-            rho *= al;
-            const float f = ratio_or_zero(al, alp);
+                for (int u = 0; u < TPW; ++u)
 #pragma unroll
-            for (int kt = 0; kt < NP / 16; ++kt) G[kt] = (G[kt] - rho) * f;
+                    for (int e = 0; e < 4; ++e) rho[u] += G[u][kt][e] * P0(u, kt, e) * b4[e];
+                SK_KEEP_ORDER();
+            }
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                float r = rho[u];
+                r += __shfl_xor(r, 16, 64);
+                r += __shfl_xor(r, 32, 64);
+                r *= av[u][t + 1];
+                const float f = ratio_or_zero(av[u][t + 1], av[u][t]);
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) G[u][kt] = (G[u][kt] - r) * f;
+            }
         }
         if (t == 0) break;
-        {   // column step with beta = b_t, beta_prev = b_{t-1}, alpha = a_t
-            const float al = av[t];
+        {   // column step with beta = b_t, beta_prev = b_{t-1}, alpha = a_t: the two tiles' contributions are added before
+            // the 16-lane reduction
 #pragma unroll
-            for (int kt = 0; kt < NP / 16; ++kt)
+            for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = row16_sum(active ? G[kt][e] * al * P0(kt, e) : 0.f);
+                    float x = 0.f;                                       // av = 0 for inactive tiles
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) x += G[u][kt][e] * av[u][t] * P0(u, kt, e);
+                    const float v = row16_sum(x);
                     if (qc == 0) colpart[wave * NP + kt * 16 + 4 * g + e] = v;
-                }
+                    if (e == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 reduction chains in flight: hipcc otherwise
+                }                                                       // interleaves all 4 NT of them (2 live registers each)
             __syncthreads();
-            for (int j = tid; j < NP; j += SK_THREADS) {
+            for (int j = tid; j < NP; j += SKQ_THREADS) {
                 float c = 0.f;
-                for (int w = 0; w < nqt; ++w) c += colpart[w * NP + j];
+#pragma unroll
+                for (int w = 0; w < SKQ_WAVES; ++w) c += colpart[w * NP + j];
                 kap[j] = c * bv[t * NP + j];
             }
             __syncthreads();
             const float* bt = bv + t * NP;
             const float* bp = bv + (t - 1) * NP;
 #pragma unroll
-            for (int kt = 0; kt < NP / 16; ++kt) {
+            for (int kt = 0; kt < NT; ++kt) {
                 const f32x4_t k4 = *reinterpret_cast<const f32x4_t*>(kap + kt * 16 + 4 * g);
                 const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bt + kt * 16 + 4 * g);
                 const f32x4_t q4 = *reinterpret_cast<const f32x4_t*>(bp + kt * 16 + 4 * g);
+                f32x4_t r4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) G[kt][e] = (G[kt][e] - k4[e]) * ratio_or_zero(b4[e], q4[e]);
+                for (int e = 0; e < 4; ++e) r4[e] = ratio_or_zero(b4[e], q4[e]);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) G[u][kt] = (G[u][kt] - k4) * r4;
+                SK_KEEP_ORDER();
             }
             __syncthreads();      // kap / colpart are rewritten by the next column step
         }
     }
     // softmax backward: dS = P0 (G - sum_j G P0) * scale
-    float sd = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NP / 16; ++kt)
+    for (int u = 0; u < TPW; ++u) {
+        float sd = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sd += G[kt][e] * P0(kt, e);
-    sd += __shfl_xor(sd, 16, 64);
-    sd += __shfl_xor(sd, 32, 64);
+        for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < NP / 16; ++kt)
+            for (int e = 0; e < 4; ++e) sd += G[u][kt][e] * P0(u, kt, e);
+        sd += __shfl_xor(sd, 16, 64);
+        sd += __shfl_xor(sd, 32, 64);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) G[kt][e] = P0(kt, e) * (G[kt][e] - sd) * p.scale;
-
-    if (!active && wave < NP / 16) {
-        // query columns nqt*16 .. NP-1 of the scratch are read (against zero Q / dO rows) by the key-owner kernel:
-        // make them finite
+        for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                wsd[(long long)(kt * 16 + 4 * g + e) * NP + q] = 0;
-                wsp[(long long)(kt * 16 + 4 * g + e) * NP + q] = 0;
-            }
+            for (int e = 0; e < 4; ++e) G[u][kt][e] = P0(u, kt, e) * (G[u][kt][e] - sd) * p.scale;
     }
-    if (active) {
+
 #pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt)
+    for (int u = 0; u < TPW; ++u) {
+        const int tile = wave + SKQ_WAVES * u;
+        if (!active[u] && tile < NT) {
+            // query columns nqt*16 .. NP-1 of the scratch are read (against zero Q / dO rows) by the key-owner kernel:
+            // make them finite
 #pragma unroll
-            for (int e = 0; e < 4; ++e) wsd[(long long)(kt * 16 + 4 * g + e) * NP + q] = f32_to_bf16(G[kt][e]);
-        f32x4_t dq[4];
+            for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < NP / 32; ++kk) {
-            const bf16x8_t dsf = pack_frag(G[2 * kk], G[2 * kk + 1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag_img(kimg, kk * 32, dt, lane), dsf, dq[dt]);
+                for (int e = 0; e < 4; ++e) {
+                    ws_store(rwd, u, kt, e, 0);
+                    ws_store(rwp, u, kt, e, 0);
+                }
         }
-        if (q < N) {
-            bf16_t* dst = p.dqkv + ((long long)b * N + q) * ldq + h * DH + 4 * g;
+        if (active[u]) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, dq[dt]);
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ws_store(rwd, u, kt, e, f32_to_bf16(G[u][kt][e]));
+            f32x4_t dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NP / 32; ++kk) {
+                const bf16x8_t dsf = pack_frag(G[u][2 * kk], G[u][2 * kk + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag_img(kimg, kk * 32, dt, lane), dsf, dq[dt]);
+            }
+            if (q[u] < N) {
+                bf16_t* dst = p.dqkv + ((long long)b * N + q[u]) * ldq + h * DH + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, dq[dt]);
+            }
         }
     }
 }
@@ -454,15 +510,16 @@ int launch_sk_fwd(const SinkParams& p, hipStream_t s) {
 
 template <int NP>
 int launch_sk_bwd(const SinkParams& p, hipStream_t s) {
-    constexpr int lds_q = 2 * NP * 128 + (5 + SK_WAVES) * NP * 4;
+    constexpr int TPW = NRV_SK_TPW;
+    constexpr int lds_q = 2 * NP * 128 + (5 + 16 / TPW) * NP * 4;
     constexpr int lds_kv = 2 * NP * 128;
-    static int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_q_kernel<NP>),
+    static int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_q_kernel<NP, TPW>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
     static int attr2 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_kv_kernel<NP>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     if (attr1 != 0) return attr1;
     if (attr2 != 0) return attr2;
-    hipLaunchKernelGGL((sinkhorn_bwd_q_kernel<NP>), dim3(p.B * p.H), dim3(SK_THREADS), lds_q, s, p);
+    hipLaunchKernelGGL((sinkhorn_bwd_q_kernel<NP, TPW>), dim3(p.B * p.H), dim3(1024 / TPW), lds_q, s, p);
     NRV_CHECK_LAUNCH();
     hipLaunchKernelGGL((sinkhorn_bwd_kv_kernel<NP>), dim3(p.B * p.H), dim3(SKB_THREADS), lds_kv, s, p);
     NRV_CHECK_LAUNCH();
