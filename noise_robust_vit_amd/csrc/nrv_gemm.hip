@@ -421,7 +421,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
         tm = id / p.tiles_n;
         tn = id - tm * p.tiles_n;
     }
+#ifdef NRV_DEV_SAME_TILE
+    // experiment (tools/build_dev.py only; results are garbage): every workgroup loads and stores tile (0, 0), so that all
+    // operand traffic hits the XCD's L2: the K loop at a 100 % L2 hit rate
+    const int m0 = 0 * tm, n0 = 0 * tn;
+#else
     const int m0 = tm * C::TBM, n0 = tn * C::TBN;
+#endif
     const int M = p.e.M, N = p.e.N, K = p.K;
 
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
