@@ -158,6 +158,64 @@ void run2(const char* name, const char* src, unsigned long long* dout, float* si
     printf("%-78s %7.0f cycles / K-tile (MFMA alone 2048)\n", name, (double)h[grid / 2] / iters);
 }
 
+// same K-tile mix on the 32x32x16 MFMA: 32 MFMAs per wave (32 cycles each: the same 2048 cycles per SIMD), which hold the
+// SIMD's vector issue for 8 of their 32 cycles instead of 8 of 16
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <int NDMA, int LIGHT>
+__global__ __launch_bounds__(512, 2) void k3(const char* src, unsigned long long* out, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* base = src + (size_t)blockIdx.x * 65536;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 65536, 0x00020000);
+    f32x16_t acc[8];
+    bf16x8_t a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+    a[0] = (short)lane; b[1] = (short)tid;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < NDMA) {
+                char* dst = smem + buf * 65536 + ((g * 8 + wave) & 63) * 1024;
+                if (LIGHT) {
+                    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(dst));
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                                 :: "v"((unsigned)lane * 16), "s"(rs), "s"(lds_addr), "s"((unsigned)(((g * 8 + wave) & 63) * 1024)) : "memory");
+                } else dma16s(rs, dst, (unsigned)lane * 16, (unsigned)(((g * 8 + wave) & 63) * 1024));
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[(g * 4 + m) & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[(g * 4 + m) & 7], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+    if (s == 12345.678f) sink[0] = s + smem[tid];
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+}
+template <int NDMA, int LIGHT>
+void run3(const char* name, const char* src, unsigned long long* dout, float* sink, int grid) {
+    const int iters = 400;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k3<NDMA, LIGHT>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((k3<NDMA, LIGHT>), dim3(grid), dim3(512), 131072, 0, src, dout, iters, sink);
+        hipDeviceSynchronize();
+    }
+    std::vector<unsigned long long> h(grid);
+    hipMemcpy(h.data(), dout, grid * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    printf("%-78s %7.0f cycles / K-tile (MFMA alone 2048)\n", name, (double)h[grid / 2] / iters);
+}
+
 int main() {
     const int grid = 256;
     char* src; unsigned long long* dout; float* sink;
@@ -176,5 +234,8 @@ int main() {
     run2<2, 0>("same, waves 0-3 issue in groups 0-3 (2 each), waves 4-7 in groups 4-7", src, dout, sink, grid);
     run2<0, 1>("DMA at group start, light M0 handling (no save/restore, s_nop 1)", src, dout, sink, grid);
     run2<1, 1>("out of phase + light M0 handling", src, dout, sink, grid);
+    run3<0, 0>("32x32x16 MFMA: 32 MFMA per wave, no DMA", src, dout, sink, grid);
+    run3<8, 0>("32x32x16 MFMA: 8 DMA + 32 MFMA per wave", src, dout, sink, grid);
+    run3<8, 1>("32x32x16 MFMA: 8 DMA + 32 MFMA per wave, light M0 handling", src, dout, sink, grid);
     return 0;
 }
