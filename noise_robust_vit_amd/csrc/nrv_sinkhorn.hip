@@ -197,15 +197,16 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_fwd_kernel(const SinkPara
 
 // ---------------------------------------------------------------------------------------------
 // backward, query-owner kernel: dQ, and dS^T / P7^T scratch for the key-owner kernel.
-// 8 FAT waves (2 per SIMD, <= 256 VGPRs), each owning TWO 16-query tiles (wave w: tiles w and w + 8): a tile's state is
-// G (fp32, NP / 4 registers) + P0 (packed bf16, NP / 8) and it lives through seven normalisation steps.  The round-1 form
-// (16 waves x one tile = 4 waves per SIMD, 128 VGPRs) spilled 488 registers to scratch at N = 197 and took 3.5 ms per
-// layer on ViT-B/16 (batch 256).  K / V row fragments are read from LDS once per key tile and feed both query tiles.
+// 8 FAT waves (2 per SIMD, <= 256 VGPRs), each owning TWO 16-query tiles (wave w: tiles w and w + 8).  The only N x N
+// state a tile keeps in registers is G (fp32, NP / 4 registers), walked back through the seven normalisations in place;
+// **P0 is recomputed on the MFMA every time it is needed** (S^T = K Q^T, 2 MFMAs + 4 exp2 per key tile and query tile, ten
+// passes per head): the MFMA pipe is otherwise idle in this kernel, and with P0 also resident (round 1: 16 waves x one tile
+// at 128 VGPRs, 488 spilled registers; first round-2 form: 82) the column steps reloaded G from scratch and took 1.6 of the
+// kernel's 2.3 ms per layer (ablation builds, tools/sinkhorn_bench.py).
 // ---------------------------------------------------------------------------------------------
 // hipcc unrolls the key-tile loops fully (the register arrays need static indices) and then hoists every LDS vector load of
-// every iteration to the top: hundreds of live registers, spilled.  A compiler-level memory fence per iteration keeps the
-// loads where they are written (no instruction is emitted).
-#define SK_KEEP_ORDER() asm volatile("" ::: "memory")
+// every iteration to the top: a compiler-level memory fence per iteration keeps the loads where they are written.
+#define SK_KEEP_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 template <int NP, int TPW>          // TPW = query tiles per wave: 16 / TPW waves
 __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_kernel(const SinkParams p) {
@@ -235,13 +236,15 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
 
     const int g = lane >> 4, qc = lane & 15;
     const int nqt = (N + 15) >> 4;
+    const float sc = p.scale * LOG2E;
     bool active[TPW], q_ok[TPW];
     int q[TPW];
-    float av[TPW][5];                 // a0 = 1, a1 .. a4 of the lane's query, per tile
-    unsigned p0h[TPW][NP / 8];        // P0, packed bf16 pairs: element e of key tile kt in half (e & 1) of word 2 kt + (e >> 1)
-    f32x4_t G[TPW][NT];               // G = dP7^T (fp32), walked back through the normalisations in place
+    float av[TPW][5];               // a0 = 1, a1 .. a4 of the lane's query, per tile
+    float lse2[TPW];
+    bf16x8_t qf[TPW][2];            // Q fragments: kept for the P0 recomputation
+    f32x4_t G[TPW][NT];             // G = dP7^T (fp32), walked back through the normalisations in place
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {        // one tile after the other: only one tile's Q / dO fragments are live at a time
+    for (int u = 0; u < TPW; ++u) {
         const int tile = wave + SKQ_WAVES * u;
         active[u] = tile < nqt;
         q[u] = tile * 16 + qc;
@@ -250,45 +253,47 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
         av[u][0] = q_ok[u] ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) av[u][t + 1] = q_ok[u] ? scal[(2 * t) * N + qr] : 0.f;
-        bf16x8_t qf[2], dof[2];
+        bf16x8_t dof[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
+            qf[u][ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
             dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
         }
-        const float lse2 = p.lse[(long long)bh * N + qr] * LOG2E;
-        const float sc = p.scale * LOG2E;
+        lse2[u] = q_ok[u] ? p.lse[(long long)bh * N + qr] * LOG2E : INFINITY;      // exp2(s - inf) = 0: padded queries need no mask
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             SK_KEEP_ORDER();
-            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
             G[u][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                st = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[ks], st);
-                G[u][kt] = mfma16(row_frag_img(vimg, kt * 16, ks, lane), dof[ks], G[u][kt]);
-            }
-            float pv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = kt * 16 + 4 * g + e;
-                pv[e] = (key < N && q_ok[u]) ? __builtin_amdgcn_exp2f(st[e] * sc - lse2) : 0.f;
-            }
-            p0h[u][kt * 2] = pack_bf16x2(pv[0], pv[1]);
-            p0h[u][kt * 2 + 1] = pack_bf16x2(pv[2], pv[3]);
+            for (int ks = 0; ks < 2; ++ks) G[u][kt] = mfma16(row_frag_img(vimg, kt * 16, ks, lane), dof[ks], G[u][kt]);
         }
     }
-    // unpack on every use: the empty asm makes the word opaque, otherwise hipcc keeps all 8 NT unpacked fp32 copies of P0
-    // alive next to the packed ones (the register file then overflows into scratch)
-    auto P0 = [&](int u, int kt, int e) -> float {
-        unsigned w = p0h[u][kt * 2 + (e >> 1)];
-        asm volatile("" : "+v"(w));
-        return (e & 1) ? bf16hi_to_f32(w) : bf16lo_to_f32(w);
+    // P0 of key tile kt for the wave's query tiles (zero for padded keys / queries)
+    auto p0_tiles = [&](int kt, f32x4_t (&p0)[TPW]) {
+        SK_KEEP_ORDER();
+        bf16x8_t kr[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kr[ks] = row_frag_img(kimg, kt * 16, ks, lane);
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) st = mfma16(kr[ks], qf[u][ks], st);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -lse2[u]));
+                // padded keys (>= N) can only sit in the last two key tiles (NP - N < 32): a per-element mask on every tile
+                // costs a hoisted SGPR-pair each (112 scalar registers at N = 197: spilled to VGPR lanes and read back
+                // with v_readlane + s_nop in every pass)
+                if (kt >= NT - 2) pv = (kt * 16 + 4 * g + e < N) ? pv : 0.f;
+                p0[u][e] = pv;
+            }
+        }
     };
 
-    // hand P7^T to the key-owner kernel before G is overwritten:  P7 = a4 P0 b3.  The scratch is written through buffer
-    // descriptors: the per-lane offset (key row 4 g + e, query column) is 4 registers per tile, the key tile is the scalar
-    // soffset (with plain pointers hipcc precomputes a 64-bit address per store: ~450 registers, spilled).
+    // hand P7^T to the key-owner kernel:  P7 = a4 P0 b3.  The scratch is written through buffer descriptors: the per-lane
+    // offset (key row 4 g + e, query column) is 4 registers per tile, the key tile is the scalar soffset (with plain
+    // pointers hipcc precomputes a 64-bit address per store).
     const __amdgpu_buffer_rsrc_t rwp = make_rsrc(p.ws_p + (long long)bh * NP * NP, (unsigned long long)NP * NP * 2);
     const __amdgpu_buffer_rsrc_t rwd = make_rsrc(p.ws_ds + (long long)bh * NP * NP, (unsigned long long)NP * NP * 2);
     unsigned wo[TPW][4];
@@ -300,17 +305,18 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
         __builtin_amdgcn_raw_buffer_store_b16((short)v, r, wo[u][e], kt * 16 * NP * 2, 0);
     };
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        if (active[u]) {
+    for (int kt = 0; kt < NT; ++kt) {
+        f32x4_t p0[TPW];
+        p0_tiles(kt, p0);
+        const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
+        for (int u = 0; u < TPW; ++u) {
+            if (active[u]) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    ws_store(rwp, u, kt, e, f32_to_bf16(av[u][4] * P0(u, kt, e) * b3[e]));
-                SK_KEEP_ORDER();
+                for (int e = 0; e < 4; ++e) ws_store(rwp, u, kt, e, f32_to_bf16(av[u][4] * p0[u][e] * b3[e]));
             }
         }
+        SK_KEEP_ORDER();
     }
 
     // walk the normalisations backwards: steps 7 (row) 6 (col) 5 (row) 4 (col) 3 (row) 2 (col) 1 (row)
@@ -324,12 +330,13 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
             for (int u = 0; u < TPW; ++u) rho[u] = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
+                f32x4_t p0[TPW];
+                p0_tiles(kt, p0);
                 const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bt + kt * 16 + 4 * g);
 #pragma unroll
                 for (int u = 0; u < TPW; ++u)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rho[u] += G[u][kt][e] * P0(u, kt, e) * b4[e];
-                SK_KEEP_ORDER();
+                    for (int e = 0; e < 4; ++e) rho[u] += G[u][kt][e] * p0[u][e] * b4[e];
             }
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
@@ -343,58 +350,71 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
             }
         }
         if (t == 0) break;
-        {   // column step with beta = b_t, beta_prev = b_{t-1}, alpha = a_t: the two tiles' contributions are added before
-            // the 16-lane reduction
+        {   // column step with beta = b_t, beta_prev = b_{t-1}, alpha = a_t: the tiles' contributions are added before the
+            // 16-lane reduction
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4_t p0[TPW];
+                p0_tiles(kt, p0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = 0.f;                                       // av = 0 for inactive tiles
 #pragma unroll
-                    for (int u = 0; u < TPW; ++u) x += G[u][kt][e] * av[u][t] * P0(u, kt, e);
+                    for (int u = 0; u < TPW; ++u) x += G[u][kt][e] * av[u][t] * p0[u][e];
                     const float v = row16_sum(x);
                     if (qc == 0) colpart[wave * NP + kt * 16 + 4 * g + e] = v;
-                    if (e == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 reduction chains in flight: hipcc otherwise
-                }                                                       // interleaves all 4 NT of them (2 live registers each)
+                }
+            }
             __syncthreads();
             for (int j = tid; j < NP; j += SKQ_THREADS) {
                 float c = 0.f;
 #pragma unroll
                 for (int w = 0; w < SKQ_WAVES; ++w) c += colpart[w * NP + j];
+                // kap = beta_j * colsum, and the ratio beta_t / beta_{t-1} of the rescale that follows (once per column
+                // here instead of once per element in every wave)
                 kap[j] = c * bv[t * NP + j];
+                colpart[j] = ratio_or_zero(bv[t * NP + j], bv[(t - 1) * NP + j]);      // row 0 of colpart is free again: all partials were read
             }
             __syncthreads();
-            const float* bt = bv + t * NP;
-            const float* bp = bv + (t - 1) * NP;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
+                SK_KEEP_ORDER();
                 const f32x4_t k4 = *reinterpret_cast<const f32x4_t*>(kap + kt * 16 + 4 * g);
-                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bt + kt * 16 + 4 * g);
-                const f32x4_t q4 = *reinterpret_cast<const f32x4_t*>(bp + kt * 16 + 4 * g);
-                f32x4_t r4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) r4[e] = ratio_or_zero(b4[e], q4[e]);
+                const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(colpart + kt * 16 + 4 * g);
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) G[u][kt] = (G[u][kt] - k4) * r4;
-                SK_KEEP_ORDER();
             }
             __syncthreads();      // kap / colpart are rewritten by the next column step
         }
     }
     // softmax backward: dS = P0 (G - sum_j G P0) * scale
+    {
+        float sd[TPW];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        float sd = 0.f;
+        for (int u = 0; u < TPW; ++u) sd[u] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4_t p0[TPW];
+            p0_tiles(kt, p0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sd += G[u][kt][e] * P0(u, kt, e);
-        sd += __shfl_xor(sd, 16, 64);
-        sd += __shfl_xor(sd, 32, 64);
+            for (int u = 0; u < TPW; ++u)
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+                for (int e = 0; e < 4; ++e) sd[u] += G[u][kt][e] * p0[u][e];
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) G[u][kt][e] = P0(u, kt, e) * (G[u][kt][e] - sd) * p.scale;
+        for (int u = 0; u < TPW; ++u) {
+            sd[u] += __shfl_xor(sd[u], 16, 64);
+            sd[u] += __shfl_xor(sd[u], 32, 64);
+        }
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4_t p0[TPW];
+            p0_tiles(kt, p0);
+#pragma unroll
+            for (int u = 0; u < TPW; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) G[u][kt][e] = p0[u][e] * (G[u][kt][e] - sd[u]) * p.scale;
+        }
     }
 
 #pragma unroll
@@ -413,14 +433,17 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
         }
         if (active[u]) {
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
+            for (int kt = 0; kt < NT; ++kt) {
+                SK_KEEP_ORDER();
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ws_store(rwd, u, kt, e, f32_to_bf16(G[u][kt][e]));
+            }
             f32x4_t dq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < NP / 32; ++kk) {
+                SK_KEEP_ORDER();
                 const bf16x8_t dsf = pack_frag(G[u][2 * kk], G[u][2 * kk + 1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag_img(kimg, kk * 32, dt, lane), dsf, dq[dt]);
