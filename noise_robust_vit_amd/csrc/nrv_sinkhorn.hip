@@ -72,8 +72,8 @@ __device__ __forceinline__ void softmax_tile(const char* kimg, const bf16x8_t (&
     for (int kt = 0; kt < NP / 16; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float v = p0[kt][e] * sc;
-            if (kt >= NP / 16 - 2) v = (kt * 16 + 4 * g + e < N) ? v : -INFINITY;      // padded keys only exist in the last two tiles
+            const int key = kt * 16 + 4 * g + e;
+            const float v = key < N ? p0[kt][e] * sc : -INFINITY;
             p0[kt][e] = v;
             m = fmaxf(m, v);
         }
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_fwd_kernel(const SinkPara
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = row16_sum(active ? a * p0[kt][e] : 0.f);
-                colpart[wave * NP + kt * 16 + 4 * g + e] = v;      // all 16 lanes of the row hold the total: same address, same value, no exec mask
+                if (qc == 0) colpart[wave * NP + kt * 16 + 4 * g + e] = v;
             }
         __syncthreads();
         for (int j = tid; j < NP; j += SK_THREADS) {                        // P /= colsum(P)
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
 #pragma unroll
                     for (int u = 0; u < TPW; ++u) x += G[u][kt][e] * av[u][t] * p0[u][e];
                     const float v = row16_sum(x);
-                    colpart[wave * NP + kt * 16 + 4 * g + e] = v;      // all 16 lanes of the row hold the total: same address, same value, no exec mask
+                    if (qc == 0) colpart[wave * NP + kt * 16 + 4 * g + e] = v;
                 }
             }
             __syncthreads();
