@@ -27,11 +27,8 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;   // TN kernel tile (and the NT "Cfg256" tile)
+constexpr int BK = 64;                      // K-tile depth of both kernels
 constexpr int GEMM_THREADS = 512;
-constexpr int STAGE_BYTES = 65536;          // A tile 32 KiB + B tile 32 KiB
-constexpr int B_TILE_OFF = 32768;
-constexpr int GEMM_LDS_BYTES = 2 * STAGE_BYTES;
 
 // NT tile configurations: WM x WN waves, each wave MI x NI MFMA tiles of 16x16 (NI is 4 everywhere: the
 // epilogue transposes 16 x 64 slabs).  One workgroup per CU.
@@ -54,6 +51,9 @@ using Cfg128 = TileCfg<2, 4, 4, 4>;      // 128x256 and 192x256: row counts that
 using Cfg192 = TileCfg<2, 4, 6, 4>;      // of the 256 CUs (MAE: 12544 rows x N 768 = 147 tiles of 256 rows, 198 of 192)
 using Cfg256 = TileCfg<2, 4, 8, 4>;
 using Cfg320 = TileCfg<2, 4, 10, 4>;
+// 128-column tiles (4 x 2 waves) for N that is a multiple of 128 but wastes a quarter or more of a 256-column grid
+// (N = 384: ViT-S): the same 64 KiB of operands per K-tile as Cfg256 for 3/4 of its MFMA work, but no padding columns
+using Cfg384n = TileCfg<4, 2, 6, 4>;     // 384 x 128  (256 x 128 measured slower on every shape)
 constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
 constexpr int EPI_PATCH_BYTES = 16 * EPI_ROW_F32 * 4;   // 4352 B per wave
 
@@ -563,22 +563,44 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 }
 
 // ---------------------------------------------------------------------------------------------
-// TN kernel.  LDS tile image: [64 token rows][256 cols] bf16 = 512-byte rows; the 32-byte unit u
-// of row R is stored at unit position u ^ (R & 7): conflict-free ds_read_b64_tr_b16 (a 32-lane
-// half reads 8 rows x 32 bytes).  Both operands are read with the same transposed pattern, so the
-// k-order permutation inside a 32-deep MFMA step is the same for A and B.
+// TN kernel.  LDS tile image: [64 token rows][TBM (A) / TBN (B) cols] bf16, rows of 256 / 512 / 768 bytes; the 32-byte
+// unit u of row R is stored at unit position u ^ (R & 7) (rows are multiples of 8 units, so the XOR stays inside the
+// row): conflict-free ds_read_b64_tr_b16 (a 32-lane half reads 8 rows x 32 bytes).  Both operands are read with the same
+// transposed pattern, so the k-order permutation inside a 32-deep MFMA step is the same for A and B.
+//
+// Tile configurations (8 waves as WM x WN, wave block (16 MI) x 64, 64 KiB of operands per K-tile in both):
+//   TnCfg256: 256 x 256 -- every width that is a multiple of 256 (ViT-B / L, MAE decoder)
+//   TnCfg384: 384 x 128 -- widths that are multiples of 384 / 128 but waste 25-44 % of a 256 x 256 grid (ViT-S: 384, 1152,
+//             1536): 3/4 of the MFMA work per staged byte, no padding columns
 // ---------------------------------------------------------------------------------------------
+template <int WM_, int WN_, int MI_>
+struct TnCfg {
+    static constexpr int WM = WM_, WN = WN_, MI = MI_;
+    static constexpr int TBM = WM * MI * 16, TBN = WN * 64;
+    static constexpr int RA = TBM * 2, RB = TBN * 2;                      // bytes per token row of the LDS images
+    static constexpr int A_BYTES = BK * RA, B_BYTES = BK * RB, STAGE = A_BYTES + B_BYTES;
+    static constexpr int CA = A_BYTES / 1024 / 8, CB = B_BYTES / 1024 / 8;   // DMA instructions per wave and K-tile
+    static constexpr int LDS = 2 * STAGE;
+    static_assert(WM * WN == 8, "8 waves");
+    static_assert(TBM % 128 == 0 && TBN % 128 == 0, "rows are multiples of 8 swizzle units");
+    static_assert(A_BYTES % 8192 == 0 && B_BYTES % 8192 == 0, "whole DMA instructions per wave");
+    static_assert(MI % 2 == 0, "row blocks are processed in pairs");
+};
+using TnCfg256 = TnCfg<2, 4, 8>;
+using TnCfg384 = TnCfg<4, 2, 6>;
+
+template <typename C>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / C::WN, wc = wave - wr * C::WN;
 
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
     const int split = id / p.tiles_mn;
     const int tile = id - split * p.tiles_mn;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * C::TBM, n0 = tn * C::TBN;
     const int M = p.e.M, N = p.e.N;
 
     const int t_begin = split * p.kt_per_split * BK;
@@ -590,7 +612,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     const bf16_t* abase = p.A + arow0 * p.lda + m0;
     const bf16_t* bbase = p.B + (long long)t_begin * p.ldb + n0;
     const int trem = t_end - t_begin;                       // token rows of this split (<= 0: nothing to do)
-    const int acols = M - m0 < BM ? M - m0 : BM, bcols = N - n0 < BN ? N - n0 : BN;
+    const int acols = M - m0 < C::TBM ? M - m0 : C::TBM, bcols = N - n0 < C::TBN ? N - n0 : C::TBN;
     // plain case: the records end with the last valid column of the last token row of the split, so rows >= t_end read as
     // zero through the range check and a DMA costs no vector instruction (per-lane offset constant, K position = soffset).
     // row-remapped A (class-token slot of the patch embedding): per-DMA address arithmetic, window of 2 GiB.
@@ -598,26 +620,34 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (a_remap || trem <= 0) ? 0x7fffffffull : ((unsigned long long)(trem - 1) * p.lda + acols) * 2ull);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(bbase, trem <= 0 ? 0ull : ((unsigned long long)(trem - 1) * p.ldb + bcols) * 2ull);
 
-    // staging: DMA instruction i of this wave fills token rows 2*(8 i + wave), +1 of a tile
-    int st_r[4], st_col[4];
-    unsigned va0[4], vb0[4];
+    // staging: DMA instruction i of this wave fills LDS bytes (8 i + wave) KiB .. +1 KiB of an operand image, lane-linear:
+    // lane -> (token row R, 16-byte position within the row); the swizzle is applied to the SOURCE column
+    int st_r[C::CA], st_col[C::CA];
+    unsigned va0[C::CA], vb0[C::CB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int R = 2 * (i * 8 + wave) + (lane >> 5);
-        const int ch = lane & 31;
-        const int ul = (ch >> 1) ^ (R & 7);
+    for (int i = 0; i < C::CA; ++i) {
+        const int L = (i * 8 + wave) * 1024 + lane * 16;
+        const int R = L / C::RA, pos = (L - R * C::RA) >> 4;
+        const int ul = (pos >> 1) ^ (R & 7);
         st_r[i] = R;
-        st_col[i] = (ul * 2 + (ch & 1)) * 8;
+        st_col[i] = (ul * 2 + (pos & 1)) * 8;
         va0[i] = st_col[i] < acols ? (unsigned)(((long long)R * p.lda + st_col[i]) * 2) : NRV_OOB;
-        vb0[i] = st_col[i] < bcols ? (unsigned)(((long long)R * p.ldb + st_col[i]) * 2) : NRV_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < C::CB; ++i) {
+        const int L = (i * 8 + wave) * 1024 + lane * 16;
+        const int R = L / C::RB, pos = (L - R * C::RB) >> 4;
+        const int ul = (pos >> 1) ^ (R & 7);
+        const int col = (ul * 2 + (pos & 1)) * 8;
+        vb0[i] = col < bcols ? (unsigned)(((long long)R * p.ldb + col) * 2) : NRV_OOB;
     }
     const unsigned a_step = (unsigned)(BK * p.lda * 2), b_step = (unsigned)(BK * p.ldb * 2);
 
-    // one DMA instruction d (0..3: A rows, 4..7: B rows) of K-tile kt into stage buffer buf
+    // one DMA instruction d (0 .. CA-1: A image, CA .. CA+CB-1: B image) of K-tile kt into stage buffer buf
     auto dma_one = [&](int buf, int kt, int d) {
-        char* base = smem + buf * STAGE_BYTES;
-        const bool isA = d < 4;
-        const int i = d & 3;
+        char* base = smem + buf * C::STAGE;
+        const bool isA = d < C::CA;
+        const int i = isA ? d : d - C::CA;
         if (isA) {
             if (a_remap) {
                 const int t = t_begin + kt * BK + st_r[i];
@@ -628,61 +658,72 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
                 dma16s(ra, base + (i * 8 + wave) * 1024, va0[i], (unsigned)kt * a_step);
             }
         } else {
-            dma16s(rb, base + B_TILE_OFF + (i * 8 + wave) * 1024, vb0[i], (unsigned)kt * b_step);
+            dma16s(rb, base + C::A_BYTES + (i * 8 + wave) * 1024, vb0[isA ? 0 : i], (unsigned)kt * b_step);
         }
     };
+    constexpr int ND = C::CA + C::CB;
+    constexpr int NG = C::MI, GH = C::MI / 2;            // MFMA groups per K-tile: 2 k-steps x MI/2 row-block pairs
+    constexpr int NGD = 4 < NG ? 4 : NG;                 // groups that carry the next tile's DMA issue
 
-    // transposed fragment read offsets: lane (g = l>>4, q = (l&15)>>2, pp = l&3) supplies row 4g+q (+16 r + 32 ks)
+    // transposed fragment read offsets: lane (g = l>>4, q = (l&15)>>2, pp = l&3) supplies row 4g+q (+16 r + 32 ks);
+    // one offset register per 16-column block of the wave (its unit index is not a multiple of 8 in every configuration,
+    // so the swizzle XOR is folded in here instead of at the read)
     const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
     const int Rl = 4 * fg + fq;
     const int x = Rl & 7;
-    const int a_tr = Rl * 512 + (x << 5) + fp * 8 + wr * 256;
-    const int b_tr = B_TILE_OFF + Rl * 512 + ((((wc & 1) << 2) ^ x) << 5) + fp * 8 + (wc >> 1) * 256;
-
-    f32x4_t acc[8][4];
+    int a_off[C::MI], b_off[4];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < C::MI; ++mi) a_off[mi] = Rl * C::RA + (((wr * C::MI + mi) ^ x) << 5) + fp * 8;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b_off[ni] = C::A_BYTES + Rl * C::RB + (((wc * 4 + ni) ^ x) << 5) + fp * 8;
+
+    f32x4_t acc[C::MI][4];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // fused bias gradient: db[m] = sum_t A[t,m] = (ones . A) on the MFMA; only the first column tile's workgroups do
-    // it, and each of the 4 column waves takes two of the 8 row blocks (2 extra MFMAs per k-step)
+    // it, and the WN column waves share the MI/2 row-block pairs (pair mp goes to wave column mp % WN)
+    constexpr int NBP = (GH + C::WN - 1) / C::WN;
     const bool do_bias = p.bias_ws != nullptr && tn == 0;
     const u32x4_t ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
-    f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    f32x4_t accb[NBP][2];
+#pragma unroll
+    for (int b = 0; b < NBP; ++b) accb[b][0] = accb[b][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     auto ld_a = [&](const char* sa, int ks, int mi) {
-        const char* q = sa + ((a_tr ^ (mi << 5)) + ks * (32 * 512));
-        return cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+        const char* q = sa + a_off[mi] + ks * (32 * C::RA);
+        return cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * C::RA));
     };
     auto ld_b = [&](const char* sa, int ks, int ni) {
-        const char* q = sa + ((b_tr ^ (ni << 5)) + ks * (32 * 512));
-        return cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * 512));
+        const char* q = sa + b_off[ni] + ks * (32 * C::RB);
+        return cat4(lds_read_tr16_b64(q), lds_read_tr16_b64(q + 16 * C::RB));
     };
 
     if (nk > 0) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) dma_one(0, 0, d);
+        for (int d = 0; d < ND; ++d) dma_one(0, 0, d);
     }
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const bool more = kt + 1 < nk;
-        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sa = smem + cur * C::STAGE;
         // same schedule as the NT kernel: fragment reads one MFMA group ahead, next tile's DMA issue spread over
-        // the first half of the groups
+        // the first groups
         bf16x8_t bfr[2][4], af[2][2];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bfr[0][ni] = ld_b(sa, 0, ni);
 #pragma unroll
         for (int j = 0; j < 2; ++j) af[0][j] = ld_a(sa, 0, j);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int ks = g >> 2, mp = g & 3;
-            if (g + 1 < 8) {
-                const int ks1 = (g + 1) >> 2, mp1 = (g + 1) & 3;
+        for (int g = 0; g < NG; ++g) {
+            const int ks = g / GH, mp = g % GH;
+            if (g + 1 < NG) {
+                const int ks1 = (g + 1) / GH, mp1 = (g + 1) % GH;
                 if (mp1 == 0) {
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) bfr[ks1 & 1][ni] = ld_b(sa, ks1, ni);
@@ -695,33 +736,43 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[2 * mp + j][ni] = mfma16(bfr[ks & 1][ni], af[g & 1][j], acc[2 * mp + j][ni]);
-            if (do_bias && mp == wc) {
+            if (do_bias && (mp % C::WN) == wc) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, af[g & 1][j], accb[j]);
+                for (int j = 0; j < 2; ++j) accb[mp / C::WN][j] = mfma16(ones, af[g & 1][j], accb[mp / C::WN][j]);
             }
-            if (more && g < 4) {
-                dma_one(cur ^ 1, kt + 1, 2 * g);
-                dma_one(cur ^ 1, kt + 1, 2 * g + 1);
+            if (more && g < NGD) {
+#pragma unroll
+                for (int d = g * ND / NGD; d < (g + 1) * ND / NGD; ++d) dma_one(cur ^ 1, kt + 1, d);
             }
         }
     }
     __syncthreads();
     if (do_bias && lane < 16) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wr * 128 + (2 * wc + j) * 16 + lane;
-            if (m < M) p.bias_ws[(long long)split * M + m] = accb[j][0];
+        for (int b = 0; b < NBP; ++b) {
+            const int mp = b * C::WN + wc;
+            if (mp < GH) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int m = m0 + wr * (C::MI * 16) + (2 * mp + j) * 16 + lane;
+                    if (m < M) p.bias_ws[(long long)split * M + m] = accb[b][j][0];
+                }
+            }
         }
     }
     EpiParams e = p.e;
     e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
-    epilogue_lin<NRV_EPI_NONE, true, true, 8>(acc, smem, e, m0 + wr * 128, n0 + wc * 64, lane, wave);
+    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, smem, e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane, wave);
 }
 
-// C = beta * C + sum_s slab[s]
-__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int splits,
-                                     float* __restrict__ C, long long ldc, int M, int N, float beta,
-                                     const float* __restrict__ bias_ws, float* __restrict__ dbias, float dbias_beta) {
+// C = beta * C + sum_s slab[s].  A block of 4 waves owns 64 consecutive 16-byte chunks of C; wave g sums the slabs
+// s = g, g + 4, ... (4 independent loads in flight per lane), the four partial sums meet in LDS and are added in the fixed
+// order ((p0 + p1) + (p2 + p3)): deterministic, and 4 x the loads in flight of one thread per chunk (the slabs of a ViT-S
+// weight gradient are 25-85 x 0.6-2.4 MB: the kernel is latency-bound, not bandwidth-bound).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int splits,
+                                                            float* __restrict__ C, long long ldc, int M, int N, float beta,
+                                                            const float* __restrict__ bias_ws, float* __restrict__ dbias, float dbias_beta) {
+    __shared__ f32x4_t part[4][64];
     if (bias_ws != nullptr) {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
             float s = 0.f;
@@ -730,17 +781,34 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long long 
         }
     }
     if (slabs == nullptr) return;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long long n4 = N >> 2;
     const long long total = (long long)M * n4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long m = i / n4, c = (i - m * n4) * 4;
-        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < splits; ++k)
-            s += *reinterpret_cast<const f32x4_t*>(slabs + k * slab_stride + m * N + c);
-        float* dst = C + m * ldc + c;
-        if (beta != 0.f) s += *reinterpret_cast<const f32x4_t*>(dst) * beta;
-        *reinterpret_cast<f32x4_t*>(dst) = s;
+    for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {     // block-uniform
+        const long long i = base + lane;
+        const bool ok = i < total;
+        const long long m = ok ? i / n4 : 0, c = ok ? (i - m * n4) * 4 : 0;
+        const float* src = slabs + m * N + c;
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        if (ok) {
+            int k = g;
+            for (; k + 12 < splits; k += 16) {
+                s0 += *reinterpret_cast<const f32x4_t*>(src + (long long)k * slab_stride);
+                s1 += *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 4) * slab_stride);
+                s2 += *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 8) * slab_stride);
+                s3 += *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 12) * slab_stride);
+            }
+            for (; k < splits; k += 4) s0 += *reinterpret_cast<const f32x4_t*>(src + (long long)k * slab_stride);
+        }
+        part[g][lane] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0 && ok) {
+            f32x4_t s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            float* dst = C + m * ldc + c;
+            if (beta != 0.f) s += *reinterpret_cast<const f32x4_t*>(dst) * beta;
+            *reinterpret_cast<f32x4_t*>(dst) = s;
+        }
+        __syncthreads();
     }
 }
 
@@ -807,6 +875,14 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
         const double c = (double)nrv_cdiv(nrv_cdiv(M, heights[i]) * tn, cus) * per_tile[i];
         if (i == 0 || c < best_cost * 0.999) { best = heights[i]; best_cost = c; }
     }
+    // 384 x 128 tiles where 256-column tiles would compute a padding column block (N = 384: 3 x 128 instead of 2 x 256).
+    // Cost 300 per tile from the ViT-S sweep (profiles/r02_nt_tile_sweep_128_column_tiles.txt: 52.5 vs 58.9 us on
+    // [50432 x 384 x 1152], 67.0 vs 75.8 on [50432 x 384 x 1536]; both grids take 2 rounds)
+    const int64_t tn128 = nrv_cdiv(N, 128);
+    if (tn128 * 128 < tn * 256) {
+        const double c = (double)nrv_cdiv(nrv_cdiv(M, 384) * tn128, cus) * 300.0;
+        if (c < best_cost * 0.999) { best = 1384; best_cost = c; }
+    }
     return best;
 }
 
@@ -815,20 +891,33 @@ int launch_nt(const GemmNTParams& p, hipStream_t s) {
     const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
     if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
         return launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);    // one launch per step: 256-row tiles only
+    if (tc == 1384) return launch_nt_cfg<Cfg384n, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 192) return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32, false>(p, s);
     return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32, false>(p, s);
 }
 
-int tn_splits(int64_t M, int64_t N, int64_t T) {
-    const int64_t tiles = nrv_cdiv(M, BM) * nrv_cdiv(N, BN);
+// TN launch plan: tile configuration (the one that computes the fewest padded MACs, the 384 x 128 tile weighted by its
+// higher cost per MAC) and the number of token splits that fills the CUs
+struct TnPlan { int cfg; int tiles_m, tiles_n, splits; };
+TnPlan tn_plan(int64_t M, int64_t N, int64_t T) {
+    TnPlan pl;
+    const int64_t t256 = nrv_cdiv(M, 256) * nrv_cdiv(N, 256), t384 = nrv_cdiv(M, 384) * nrv_cdiv(N, 128);
+    int want = (double)t384 * 0.75 * 1.12 < (double)t256 ? 384 : 256;
+#ifdef NRV_DEV_TN_TILE
+    want = NRV_DEV_TN_TILE;      // tools/build_dev.py only
+#endif
+    pl.cfg = want;
+    pl.tiles_m = (int)nrv_cdiv(M, want == 384 ? 384 : 256);
+    pl.tiles_n = (int)nrv_cdiv(N, want == 384 ? 128 : 256);
+    const int64_t tiles = (int64_t)pl.tiles_m * pl.tiles_n;
     const int64_t kt = nrv_cdiv(T, BK);
-    int64_t s = 256 / tiles;
-    if (s < 1) s = 1;
+    int64_t s = device_cus() / tiles;
     if (s > kt) s = kt;
     if (s < 1) s = 1;
-    return (int)s;
+    pl.splits = (int)s;
+    return pl;
 }
 
 }  // namespace
@@ -848,7 +937,7 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     if (c_dtype != NRV_F32 && c_dtype != NRV_BF16) return NRV_ERR_DTYPE;
     const int64_t csz = c_dtype == NRV_F32 ? 4 : 2;
     if (!nrv_aligned16(A) || !nrv_aligned16(B) || !nrv_aligned16(C) || ((ldc * csz) & 15)) return NRV_ERR_ALIGN;
-    if (lda * 2 * 256 >= 0x7fffffffll || ldb * 2 * 256 >= 0x7fffffffll) return NRV_ERR_SHAPE;
+    if (lda * 2 * 384 >= 0x7fffffffll || ldb * 2 * 256 >= 0x7fffffffll) return NRV_ERR_SHAPE;      // per-lane DMA row offsets within a tile
     if (out_group < 0 || (out_group > 0 && out_group_stride < out_group)) return NRV_ERR_SHAPE;
     if ((out_group > 0 || aux_row_mod > 0) && epilogue_id != NRV_EPI_BIAS_RESIDUAL) return NRV_ERR_EPILOGUE;   // nrv.h: remap rides on that epilogue
     // the epilogue addresses a wave's block (<= 160 rows) with 32-bit byte offsets
@@ -905,7 +994,7 @@ extern "C" int nrv_dev_read_stamps(unsigned long long* host_out, size_t count) {
 
 extern "C" size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T) {
     if (M <= 0 || N <= 0 || T <= 0) return 0;
-    const int s = tn_splits(M, N, T);
+    const int s = tn_plan(M, N, T).splits;
     return (size_t)s * (size_t)M * (size_t)N * 4 + (size_t)s * (size_t)M * 4;   // C slabs (also the beta == 1 single-split case) + bias slabs
 }
 
@@ -921,7 +1010,8 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     if (!nrv_aligned16(A) || !nrv_aligned16(B) || !nrv_aligned16(C)) return NRV_ERR_ALIGN;
     if (beta != 0.f && beta != 1.f) return NRV_ERR_SHAPE;
     if (a_group < 0 || (a_group > 0 && a_group_stride < a_group)) return NRV_ERR_SHAPE;
-    const int splits = tn_splits(M, N, T);
+    const TnPlan pl = tn_plan(M, N, T);
+    const int splits = pl.splits;
     const int64_t kt_total = nrv_cdiv(T, BK);
     const int kt_per_split = (int)nrv_cdiv(kt_total, splits);
     // per-workgroup operand windows must stay below 2 GiB of byte offset
@@ -938,8 +1028,7 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.A = static_cast<const bf16_t*>(A);
     p.B = static_cast<const bf16_t*>(B);
     p.lda = lda; p.ldb = ldb; p.T = (int)T;
-    const int tiles_m = (int)nrv_cdiv(M, BM), tiles_n = (int)nrv_cdiv(N, BN);
-    p.tiles_n = tiles_n; p.tiles_mn = tiles_m * tiles_n;
+    p.tiles_n = pl.tiles_n; p.tiles_mn = pl.tiles_m * pl.tiles_n;
     p.splits = splits; p.kt_per_split = kt_per_split;
     p.a_group = (int)a_group; p.a_group_stride = (int)a_group_stride; p.a_row_offset = (int)a_row_offset;
     p.e.bias = nullptr; p.e.aux = nullptr; p.e.aux_out = nullptr;
@@ -951,14 +1040,20 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.bias_ws = dbias ? reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes) : nullptr;
 
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static int attr = set_lds(gemm_tn_kernel, GEMM_LDS_BYTES);
-    if (attr != 0) return attr;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, p);
+    if (pl.cfg == 384) {
+        static int attr = set_lds(gemm_tn_kernel<TnCfg384>, TnCfg384::LDS);
+        if (attr != 0) return attr;
+        hipLaunchKernelGGL(gemm_tn_kernel<TnCfg384>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg384::LDS, s, p);
+    } else {
+        static int attr = set_lds(gemm_tn_kernel<TnCfg256>, TnCfg256::LDS);
+        if (attr != 0) return attr;
+        hipLaunchKernelGGL(gemm_tn_kernel<TnCfg256>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg256::LDS, s, p);
+    }
     NRV_CHECK_LAUNCH();
     if (!direct || dbias) {
         const long long total4 = direct ? (long long)nrv_cdiv(M, 4) : (long long)M * (N >> 2);
-        int blocks = (int)((total4 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (int)((total4 + 63) / 64);            // 64 chunks of C per block
+        if (blocks > 8192) blocks = 8192;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s,
                            direct ? nullptr : static_cast<const float*>(workspace), (long long)M * N, splits, C, (long long)ldc,

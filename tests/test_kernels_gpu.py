@@ -259,7 +259,9 @@ def test_gemm_nt_row_remap(dev):
 
 # ------------------------------------------------------------------ GEMM TN / colsum
 @pytest.mark.parametrize("T,M,N", [(32, 192, 192), (64, 256, 256), (1000, 768, 768), (3000, 576, 192),
-                                   (5000, 3072, 768), (777, 104, 72), (4096, 768, 3072), (50, 384, 1536)])
+                                   (5000, 3072, 768), (777, 104, 72), (4096, 768, 3072), (50, 384, 1536),
+                                   # widths the 384 x 128 tile serves (ViT-S: 384 / 1152 / 1536) and ragged edges of it
+                                   (3000, 1152, 384), (2100, 384, 384), (1500, 1536, 384), (900, 400, 136), (130, 776, 120)])
 def test_gemm_tn(dev, T, M, N):
     k = _k()
     A = rnd((T, M), dev, 40)
@@ -285,6 +287,22 @@ def test_gemm_tn_identity_asymmetric(dev):
     B = (torch.arange(T * N, device=dev, dtype=torch.float32).reshape(T, N) % 11 - 5).to(torch.bfloat16)
     c = k.gemm_tn(A, B)
     assert torch.equal(c, B.float())
+
+
+def test_gemm_tn_identity_384x128_tile(dev):
+    """A = I: the result is B itself, so any mix-up of the 768-byte-row LDS image (row split of a DMA instruction, swizzle,
+    wave-block unit offsets) shows as a misplaced column."""
+    k = _k()
+    T = M = 384
+    N = 128
+    A = torch.eye(T, dtype=torch.bfloat16, device=dev)
+    B = (torch.arange(T * N, device=dev, dtype=torch.float32).reshape(T, N) % 13 - 6).to(torch.bfloat16)
+    c = k.gemm_tn(A, B)
+    assert torch.equal(c, B.float())
+    A2 = (torch.arange(T * M, device=dev, dtype=torch.float32).reshape(T, M) % 7 - 3).to(torch.bfloat16)
+    B2 = torch.zeros(T, N, dtype=torch.bfloat16, device=dev)
+    B2[torch.arange(N), torch.arange(N)] = 1.0            # B = [I; 0]: C = A[:128, :]^T
+    assert torch.equal(k.gemm_tn(A2, B2), A2[:N].float().t().contiguous())
 
 
 def test_gemm_tn_row_remap(dev):

@@ -10,7 +10,7 @@ from noise_robust_vit_amd import kernels as K
 from noise_robust_vit_amd._lib import *
 
 dev = torch.device("cuda:0")
-libs = ["t128", "t192", "t256", "t320", "product"]
+libs = os.environ.get("libs", "t128,t192,t256,t320").split(",") + ["product"]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 def rnd(*s, dt=torch.bfloat16): return (torch.randn(*s, device=dev) * 0.5).to(dt)
 def timeit(fn, n=6):
@@ -44,9 +44,15 @@ for title, shapes in sets.items():
         fn = lambda: K.gemm_nt(A, B, epilogue=epi, bias=bias if epi in (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL) else None,
                                aux=aux, aux_out=aux_out, out=out)
         res = {l: [] for l in libs}
+        outs = {}
         for l in libs:
             _devlib.use_library(l); fn(); fn()
+            outs[l] = out.float().clone()
         torch.cuda.synchronize()
+        bad = [l for l in libs if not torch.equal(outs[l], outs["product"])]       # same K order in every tile shape: bit-equal
+        if bad: print(f"  !! {name}: results of {bad} differ from the product build "
+                      f"(max {max(float((outs[l] - outs['product']).abs().max()) for l in bad):.3e})")
+        del outs
         for _ in range(rounds):
             for l in libs:
                 _devlib.use_library(l); res[l].append(timeit(fn))
