@@ -124,35 +124,37 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 // Issued through inline asm so that hipcc's waitcnt pass does not know an LDS-DMA is in flight: with the builtin
 // it drains vmcnt(0) in front of every later ds_read_b64_tr_b16 (seen in the TN kernel's .s), which serialises
 // load and compute.  The kernels wait for these loads themselves (s_waitcnt vmcnt(0) + barrier before the reads).
-// M0 (the LDS base of the DMA) is compiler-reserved: save / set / restore it inside the one statement.
+// M0 (the LDS base of the DMA) is written inside the statement and declared clobbered; one wait state between the
+// scalar write of M0 and the buffer instruction that reads it (what the compiler itself emits for the intrinsic).  Saving and
+// restoring M0 around the load with 5 wait states cost the GEMM K loops 2-3 % (profiles/r02_ab_light_m0.txt).
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset) {
     const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_base));
-    unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 4\n\t"
-        "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %1, 0 offen lds"
+        :
         : "v"(voffset), "s"(rsrc), "s"(lds_addr)
-        : "memory");
+        : "memory", "m0");
 }
 
 // the same with a scalar byte offset added by the memory unit (soffset): a K loop advances the SCALAR and keeps the per-lane
 // offset constant, so a DMA costs no vector-ALU instruction (the range check subtracts soffset from the record count)
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset, unsigned soffset) {
     const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_base));
+#ifdef NRV_DEV_OLD_M0
     unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voffset), "s"(rsrc), "s"(lds_addr), "s"(soffset) : "memory");
+#else
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 4\n\t"
-        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %1, %3 offen lds"
+        :
         : "v"(voffset), "s"(rsrc), "s"(lds_addr), "s"(soffset)
-        : "memory");
+        : "memory", "m0");
+#endif
 }
 
 __device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {

@@ -569,9 +569,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 // transposed pattern, so the k-order permutation inside a 32-deep MFMA step is the same for A and B.
 //
 // Tile configurations (8 waves as WM x WN, wave block (16 MI) x 64, 64 KiB of operands per K-tile in both):
-//   TnCfg256: 256 x 256 -- every width that is a multiple of 256 (ViT-B / L, MAE decoder)
-//   TnCfg384: 384 x 128 -- widths that are multiples of 384 / 128 but waste 25-44 % of a 256 x 256 grid (ViT-S: 384, 1152,
-//             1536): 3/4 of the MFMA work per staged byte, no padding columns
+//   TnCfg256: 256 x 256 -- the product's only TN tile
+//   TnCfg384: 384 x 128 -- developer builds only (-DNRV_DEV_TN_TILE=384): removes the 25-44 % padding of a 256 x 256 grid on
+//             the ViT-S widths (384, 1152, 1536) and wins in isolated launches, loses inside the step (tn_plan)
 // ---------------------------------------------------------------------------------------------
 template <int WM_, int WN_, int MI_>
 struct TnCfg {
@@ -837,6 +837,9 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
     const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
     p.tiles_n = tiles_n;
     p.gn = 4;               // column groups of 4 tiles per XCD (swept 2, 3, 4, 6, 12, off in round 1: 8192^3 1111 -> 1336 TFLOP/s)
+#ifdef NRV_DEV_GN
+    p.gn = NRV_DEV_GN;      // tools/build_dev.py only
+#endif
 #ifdef NRV_DEV_STAMPS
     p.stamps = debug_stamp_buffer();
 #endif
@@ -879,7 +882,11 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
     // Cost 300 per tile from the ViT-S sweep (profiles/r02_nt_tile_sweep_128_column_tiles.txt: 52.5 vs 58.9 us on
     // [50432 x 384 x 1152], 67.0 vs 75.8 on [50432 x 384 x 1536]; both grids take 2 rounds)
     const int64_t tn128 = nrv_cdiv(N, 128);
+#ifdef NRV_DEV_NO_NARROW
+    if (false) {
+#else
     if (tn128 * 128 < tn * 256) {
+#endif
         const double c = (double)nrv_cdiv(nrv_cdiv(M, 384) * tn128, cus) * 300.0;
         if (c < best_cost * 0.999) { best = 1384; best_cost = c; }
     }
@@ -903,8 +910,10 @@ int launch_nt(const GemmNTParams& p, hipStream_t s) {
 struct TnPlan { int cfg; int tiles_m, tiles_n, splits; };
 TnPlan tn_plan(int64_t M, int64_t N, int64_t T) {
     TnPlan pl;
-    const int64_t t256 = nrv_cdiv(M, 256) * nrv_cdiv(N, 256), t384 = nrv_cdiv(M, 384) * nrv_cdiv(N, 128);
-    int want = (double)t384 * 0.75 * 1.12 < (double)t256 ? 384 : 256;
+    // In isolated back-to-back launches the 384 x 128 tile wins wherever it removes padding (ViT-S dWqkv 72 -> 64 us), but
+    // inside the training step, where the operands are not already in the Infinity Cache, it loses (ViT-S TN total 3.93 ->
+    // 4.18 ms per step: more operand panels per workgroup): profiles/r02_step_ab_in_process.txt.  Developer builds only.
+    int want = 256;
 #ifdef NRV_DEV_TN_TILE
     want = NRV_DEV_TN_TILE;      // tools/build_dev.py only
 #endif
@@ -1040,11 +1049,14 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.bias_ws = dbias ? reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes) : nullptr;
 
     hipStream_t s = static_cast<hipStream_t>(stream);
+#ifdef NRV_DEV_TN_TILE
     if (pl.cfg == 384) {
         static int attr = set_lds(gemm_tn_kernel<TnCfg384>, TnCfg384::LDS);
         if (attr != 0) return attr;
         hipLaunchKernelGGL(gemm_tn_kernel<TnCfg384>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg384::LDS, s, p);
-    } else {
+    } else
+#endif
+    {
         static int attr = set_lds(gemm_tn_kernel<TnCfg256>, TnCfg256::LDS);
         if (attr != 0) return attr;
         hipLaunchKernelGGL(gemm_tn_kernel<TnCfg256>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg256::LDS, s, p);

@@ -4,7 +4,8 @@
     python tools/gemm_bench.py                       # the product library
     python tools/gemm_bench.py product,exp1 [rounds]  # interleaved A/B of tools/_build/libnrv_hip_exp1.so vs the product
                                                       # in ONE process on ONE device (guide rule 24): median / min per build
-Shapes: T = 50432 rows unless T=... in the environment; `only=nt|tn|misc` restricts the sections."""
+Shapes: T = 50432 rows unless T=... in the environment; `only=nt|tn|misc` restricts the sections; `cold=1` evicts the caches
+before every timed call (back-to-back repetitions keep ViT-S-sized operands in the 256 MB Infinity Cache, a training step does not)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import statistics
@@ -21,7 +22,17 @@ libs = (sys.argv[1] if len(sys.argv) > 1 else "product").split(",")
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 def rnd(*s, dt=torch.bfloat16): return (torch.randn(*s, device=dev) * 0.5).to(dt)
 
+cold = os.environ.get("cold", "") == "1"       # cold=1: evict L2 / Infinity Cache before every timed call (in-step conditions:
+_flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev) if cold else None     # the operands were not just read)
 def timeit(fn, n=8):
+    if cold:
+        tot = 0.0
+        for _ in range(n):
+            _flush.add_(1)
+            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            s.record(); fn(); e.record(); torch.cuda.synchronize()
+            tot += s.elapsed_time(e)
+        return tot / n
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n): fn()
