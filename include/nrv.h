@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 7
+#define NRV_ABI_VERSION 8
 
 /* dtype codes */
 #define NRV_F32 0
@@ -155,14 +155,11 @@ int nrv_attn_probs(const void* qkv_bf16, const float* lse, float* probs,
 /* "robust" attention (robust=True): softmax followed by Sinkhorn normalisation -- 3 x (row /, column /) and a final
  * row / -- utils.py:1025-1037, wired at simple_vit.py:56-57.  Same layouts as nrv_attn_fwd.
  *   scalings fp32 [B, H, 7, N]: the row / column scaling vectors a1 b1 a2 b2 a3 b3 a4 (cumulative: after step t, P = diag(a_t) softmax(S) diag(b_t); the final matrix is diag(a4) softmax(S) diag(b3)),
- *   saved with lse for the backward.  dh == 64, N <= 256.
- *   Backward scratch: nrv_attn_sinkhorn_bwd_workspace(B, N, H) bytes (bf16 dS^T and P^T per head). */
+ *   saved with lse for the backward.  dh == 64, N <= 256.  The backward is one kernel and needs no scratch (ABI 8). */
 int nrv_attn_sinkhorn_fwd(const void* qkv_bf16, void* out_bf16, float* lse, float* scalings,
                           int B, int N, int H, int dh, float scale, void* stream);
-size_t nrv_attn_sinkhorn_bwd_workspace(int B, int N, int H);
 int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16, const float* lse, const float* scalings,
-                          void* dqkv_bf16, void* workspace, size_t workspace_bytes,
-                          int B, int N, int H, int dh, float scale, void* stream);
+                          void* dqkv_bf16, int B, int N, int H, int dh, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch unfold (replaces einops Rearrange 'b c (h p1) (w p2) -> b h w (p1 p2 c)' simple_vit.py:126-129,

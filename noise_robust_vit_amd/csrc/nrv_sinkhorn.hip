@@ -16,9 +16,9 @@
 // Backward (query-owner kernel): recompute P0, G = dP7 = dO V^T, walk the 7 normalisations backwards
 //     row step:  G_ij <- (G_ij - alpha_i sum_j G_ij P0_ij beta_j) * alpha_i / alpha_prev_i
 //     col step:  G_ij <- (G_ij - beta_j sum_i G_ij alpha_i P0_ij) * beta_j / beta_prev_j
-// then the softmax backward, dQ = dS K on MFMA, and dS / P7 are handed to the key-owner kernel as bf16 [key][q]
-// scratch (the only [N,N] traffic of the robust path; the reference materialises ~10 fp32 copies).
-// Key-owner kernel: dK = dS^T Q, dV = P7^T dO (pure MFMA, transposed LDS reads of Q / dO).
+// then the softmax backward and dQ = dS K on MFMA.  dK = dS^T Q and dV = P7^T dO contract over queries: P7 / dS are
+// transposed through an LDS chunk inside the same kernel (nothing [N,N]-sized ever reaches HBM; the reference materialises
+// ~10 fp32 copies).
 #include "nrv_attn_common.hpp"
 
 namespace {
@@ -27,7 +27,6 @@ using namespace nrv_attn;
 
 constexpr int SK_THREADS = 1024;      // 16 waves: one 16-query tile each (N <= 256)
 constexpr int SK_WAVES = 16;
-constexpr int SKB_THREADS = 512;      // key-owner backward kernel
 #ifndef NRV_SK_TPW
 #define NRV_SK_TPW 2
 #endif
@@ -39,8 +38,9 @@ struct SinkParams {
     bf16_t* dqkv;          // [B, N, 3*H*64]
     float* lse;            // [B, H, N]
     float* scal;           // [B, H, 7, N]   a1 b1 a2 b2 a3 b3 a4
-    bf16_t* ws_ds;         // [B*H, NP, NP]  dS^T  [key][q]   (backward scratch)
-    bf16_t* ws_p;          // [B*H, NP, NP]  P7^T  [key][q]
+#ifdef NRV_SK_STAMPS
+    unsigned long long* stamps;      // tools/ build only: 16 phase stamps per workgroup
+#endif
     int B, N, H;
     float scale;
 };
@@ -195,44 +195,96 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_fwd_kernel(const SinkPara
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// backward, query-owner kernel: dQ, and dS^T / P7^T scratch for the key-owner kernel.
-// 8 FAT waves (2 per SIMD, <= 256 VGPRs), each owning TWO 16-query tiles (wave w: tiles w and w + 8).  The only N x N
-// state a tile keeps in registers is G (fp32, NP / 4 registers), walked back through the seven normalisations in place;
-// **P0 is recomputed on the MFMA every time it is needed** (S^T = K Q^T, 2 MFMAs + 4 exp2 per key tile and query tile, ten
-// passes per head): the MFMA pipe is otherwise idle in this kernel, and with P0 also resident (round 1: 16 waves x one tile
-// at 128 VGPRs, 488 spilled registers; first round-2 form: 82) the column steps reloaded G from scratch and took 1.6 of the
-// kernel's 2.3 ms per layer (ablation builds, tools/sinkhorn_bench.py).
-// ---------------------------------------------------------------------------------------------
 // hipcc unrolls the key-tile loops fully (the register arrays need static indices) and then hoists every LDS vector load of
 // every iteration to the top: a compiler-level memory fence per iteration keeps the loads where they are written.
 #define SK_KEEP_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int NP, int TPW>          // TPW = query tiles per wave: 16 / TPW waves
-__global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_kernel(const SinkParams p) {
-    constexpr int SKQ_WAVES = 16 / TPW, SKQ_THREADS = 64 * SKQ_WAVES;
+// ---------------------------------------------------------------------------------------------
+// backward, ONE kernel per head: the query-owner walk above plus the key-owner products dV = P7^T dO and dK = dS^T Q, which
+// contract over QUERIES.  The walk holds P7 / dS with a lane per query and its keys in registers (the operand layout of a
+// contraction over keys: dQ = dS K); the transposition goes through an LDS chunk instead of 2 x [NP x NP] bf16 of HBM scratch
+// per head and a second kernel: the waves write their 16-query tile slot u as bf16 rows [query][key] (one 8-byte store per
+// key tile), and every wave then takes its key tiles (wave, wave + 8) and reads the chunk back with ds_read_b64_tr_b16 as the
+// MFMA operand whose k index is the query (rows = queries: the same transposed pattern as the Q / dO / K image reads).
+// LDS: K image | one image slot that holds dO (dV phase), then V (G = dO V^T), then Q (dK phase) | vectors | chunk of 128
+// queries x (NP keys + 16) bf16 (row stride = 8 dwords mod 64: the 8 rows of a transposed read hit 8 different bank groups).
+// ---------------------------------------------------------------------------------------------
+// LDS size of the one-kernel backward; with room for a third image slot the V image is loaded with K and dO at the start and
+// the Q image during the walk (both hidden), otherwise one slot holds dO, V and Q in turn
+template <int NP, int TPW>
+struct SkBwdLds {
+    static constexpr int WAVES = 16 / TPW;
+    static constexpr int CH = 16 * WAVES;                      // queries per chunk: tile slot u of every wave
+    static constexpr int RS = NP * 2 + 32;                     // chunk row stride (bytes)
+    static constexpr int VEC = (5 + WAVES) * NP * 4;
+    static constexpr bool THREE = 3 * NP * 128 + VEC + CH * RS <= 160 * 1024;
+    static constexpr int IMAGES = THREE ? 3 : 2;
+    static constexpr int BYTES = IMAGES * NP * 128 + VEC + CH * RS;
+};
+
+// LDS-DMA of one [N x 64] bf16 head slice (row stride ld elements) into a row image with the img_off swizzle (applied to the
+// SOURCE chunk: the LDS side of a DMA instruction is lane-linear); rows >= N read as zero.  Asynchronous: vmcnt.
+template <int NP, int NWAVES>
+__device__ __forceinline__ void dma_image(char* img, const bf16_t* src, long long ld, int N, int wave_u, int lane) {
+    // the head's base address is uniform but comes out of an integer division (VALU): pin it to scalar registers, the
+    // descriptor of the DMA must live in SGPRs
+    const unsigned long long a = reinterpret_cast<unsigned long long>(src);
+    const unsigned a_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));      // the builtin returns int: go through
+    const unsigned a_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);              // unsigned before widening
+    const unsigned long long au = ((unsigned long long)a_hi << 32) | (unsigned long long)a_lo;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const bf16_t*>(au), 0x7fffffffull);
+    constexpr int NI = NP / 8;
+#pragma unroll
+    for (int i = 0; i < (NI + NWAVES - 1) / NWAVES; ++i) {
+        const int j = wave_u + NWAVES * i;
+        if (j < NI) {                                          // wave-uniform
+            const int r = 8 * j + (lane >> 3), pos = lane & 7;
+            const int c = pos ^ ((r >> 1) & 7);
+            dma16(rs, img + j * 1024, r < N ? (unsigned)(r * ld * 2 + c * 16) : NRV_OOB);
+        }
+    }
+}
+
+template <int NP, int TPW>
+__global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_kernel(const SinkParams p) {
+    using L = SkBwdLds<NP, TPW>;
+    constexpr int SKQ_WAVES = L::WAVES, SKQ_THREADS = 64 * SKQ_WAVES;
+    constexpr int CH = L::CH, RS = L::RS;
+    constexpr bool THREE = L::THREE;
+    static_assert((RS / 4) % 16 == 8, "chunk rows must be 8 dwords mod 16 apart");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;                                            // row + transposed reads
-    char* vimg = smem + NP * 128;                                 // row reads
-    float* bv = reinterpret_cast<float*>(smem + 2 * NP * 128);    // [4][NP]: b0 = 1, b1, b2, b3
+    char* img1 = smem + NP * 128;                                 // dO, then (two slots: V, then) Q
+    char* vimg = smem + (THREE ? 2 : 1) * NP * 128;               // V: its own slot when there is room
+    float* bv = reinterpret_cast<float*>(smem + L::IMAGES * NP * 128);    // [4][NP]: b0 = 1, b1, b2, b3
     float* kap = bv + 4 * NP;                                     // [NP] column correction of the current step
     float* colpart = kap + NP;                                    // [SKQ_WAVES][NP]
+    char* chunk = reinterpret_cast<char*>(colpart + SKQ_WAVES * NP);
     constexpr int NT = NP / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef NRV_SK_STAMPS      // tools/build_dev.py only: phase stamps of wave 0
+    unsigned long long* stamp_out = p.stamps + (long long)blockIdx.x * 16;
+    int stamp_i = 0;
+#define SK_STAMP() do { if (tid == 0) stamp_out[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#else
+#define SK_STAMP() do { } while (0)
+#endif
+    SK_STAMP();
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N;
     const long long ldq = 3ll * p.H * DH, ldo = (long long)p.H * DH;
     const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
     const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
     const float* scal = p.scal + (long long)bh * 7 * N;
-    load_image<NP, false, SKQ_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
-    load_image<NP, false, SKQ_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
+    dma_image<NP, SKQ_WAVES>(kimg, qbase + p.H * DH, ldq, N, wave, lane);
+    dma_image<NP, SKQ_WAVES>(img1, dobase, ldo, N, wave, lane);
+    if (THREE) dma_image<NP, SKQ_WAVES>(vimg, qbase + 2 * p.H * DH, ldq, N, wave, lane);
     for (int j = tid; j < NP; j += SKQ_THREADS) {
         bv[j] = j < N ? 1.0f : 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t) bv[(t + 1) * NP + j] = j < N ? scal[(2 * t + 1) * N + j] : 0.f;
     }
-    __syncthreads();
 
     const int g = lane >> 4, qc = lane & 15;
     const int nqt = (N + 15) >> 4;
@@ -242,7 +294,6 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
     float av[TPW][5];               // a0 = 1, a1 .. a4 of the lane's query, per tile
     float lse2[TPW];
     bf16x8_t qf[TPW][2];            // Q fragments: kept for the P0 recomputation
-    f32x4_t G[TPW][NT];             // G = dP7^T (fp32), walked back through the normalisations in place
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
         const int tile = wave + SKQ_WAVES * u;
@@ -253,22 +304,25 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
         av[u][0] = q_ok[u] ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) av[u][t + 1] = q_ok[u] ? scal[(2 * t) * N + qr] : 0.f;
-        bf16x8_t dof[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[u][ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
-            dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
-        }
+        for (int ks = 0; ks < 2; ++ks) qf[u][ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
         lse2[u] = q_ok[u] ? p.lse[(long long)bh * N + qr] * LOG2E : INFINITY;      // exp2(s - inf) = 0: padded queries need no mask
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            SK_KEEP_ORDER();
-            G[u][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) G[u][kt] = mfma16(row_frag_img(vimg, kt * 16, ks, lane), dof[ks], G[u][kt]);
-        }
     }
-    // P0 of key tile kt for the wave's query tiles (zero for padded keys / queries)
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the images have landed (through the builtin: hipcc's own counting stays exact)
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    SK_STAMP();           // 1: images + vectors loaded
+    // P0 of key tile kt (zero for padded keys / queries): for all tile slots of the wave, or for one
+    auto p0_from = [&](const f32x4_t& st, int kt, int u, f32x4_t& out) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -lse2[u]));
+            // padded keys (>= N) can only sit in the last two key tiles (NP - N < 32): a per-element mask on every tile
+            // costs a hoisted SGPR-pair each (spilled to VGPR lanes and read back with v_readlane + s_nop in every pass)
+            if (kt >= NT - 2) pv = (kt * 16 + 4 * g + e < N) ? pv : 0.f;
+            out[e] = pv;
+        }
+    };
     auto p0_tiles = [&](int kt, f32x4_t (&p0)[TPW]) {
         SK_KEEP_ORDER();
         bf16x8_t kr[2];
@@ -279,47 +333,105 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
             f32x4_t st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) st = mfma16(kr[ks], qf[u][ks], st);
+            p0_from(st, kt, u, p0[u]);
+        }
+    };
+
+    // key-owner side: this wave's key tiles are wave + SKQ_WAVES s; the chunk rows are queries u CH .. of slot u
+    const int tq = (lane & 15) >> 2, tpp = lane & 3;
+    const int chunk_rd = (4 * g + tq) * RS + tpp * 8;                        // + (32 ks + {0, 16}) RS + 32 kt
+    const int chunk_wr = (wave * 16 + qc) * RS + 8 * g;                      // + 32 kt: 4 consecutive keys of the lane's query
+    auto key_owner_products = [&](f32x4_t (&acc)[TPW][4], const char* img, int u) {      // acc[s][dt] += img^T[d, q] . chunk[q, key]
+        const int rows = NP - u * CH < CH ? NP - u * CH : CH;                // multiple of 32 (NP is)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float pv = __builtin_amdgcn_exp2f(fmaf(st[e], sc, -lse2[u]));
-                // padded keys (>= N) can only sit in the last two key tiles (NP - N < 32): a per-element mask on every tile
-                // costs a hoisted SGPR-pair each (112 scalar registers at N = 197: spilled to VGPR lanes and read back
-                // with v_readlane + s_nop in every pass)
-                if (kt >= NT - 2) pv = (kt * 16 + 4 * g + e < N) ? pv : 0.f;
-                p0[u][e] = pv;
+        for (int s = 0; s < TPW; ++s) {
+            const int ktw = wave + SKQ_WAVES * s;
+            if (ktw < NT) {
+#pragma unroll
+                for (int ks = 0; ks < CH / 32; ++ks) {
+                    if (ks * 32 < rows) {
+                        SK_KEEP_ORDER();
+                        const char* a0 = chunk + chunk_rd + ks * 32 * RS + ktw * 32;
+                        const bf16x8_t cf = cat4(lds_read_tr16_b64(a0), lds_read_tr16_b64(a0 + 16 * RS));
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+                            acc[s][dt] = mfma16(tr_frag_img(img, u * CH + ks * 32, dt, lane), cf, acc[s][dt]);
+                    }
+                }
+            }
+        }
+    };
+    auto store_key_rows = [&](const f32x4_t (&acc)[TPW][4], int which /* 1: dK, 2: dV */) {
+#pragma unroll
+        for (int s = 0; s < TPW; ++s) {
+            const int key = (wave + SKQ_WAVES * s) * 16 + qc;
+            if (key < N) {
+                bf16_t* dst = p.dqkv + ((long long)b * N + key) * ldq + which * p.H * DH + h * DH + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, acc[s][dt]);
             }
         }
     };
 
-    // hand P7^T to the key-owner kernel:  P7 = a4 P0 b3.  The scratch is written through buffer descriptors: the per-lane
-    // offset (key row 4 g + e, query column) is 4 registers per tile, the key tile is the scalar soffset (with plain
-    // pointers hipcc precomputes a 64-bit address per store).
-    const __amdgpu_buffer_rsrc_t rwp = make_rsrc(p.ws_p + (long long)bh * NP * NP, (unsigned long long)NP * NP * 2);
-    const __amdgpu_buffer_rsrc_t rwd = make_rsrc(p.ws_ds + (long long)bh * NP * NP, (unsigned long long)NP * NP * 2);
-    unsigned wo[TPW][4];
+    // ---- dV = P7^T dO,  P7 = a4 P0 b3
+    {
+    f32x4_t dv[TPW][4];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u)
+    for (int s = 0; s < TPW; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wo[u][e] = (unsigned)(((4 * g + e) * NP + q[u]) * 2);
-    auto ws_store = [&](const __amdgpu_buffer_rsrc_t& r, int u, int kt, int e, unsigned short v) {
-        __builtin_amdgcn_raw_buffer_store_b16((short)v, r, wo[u][e], kt * 16 * NP * 2, 0);
-    };
+        for (int dt = 0; dt < 4; ++dt) dv[s][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-        f32x4_t p0[TPW];
-        p0_tiles(kt, p0);
-        const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
+    for (int u = 0; u < TPW; ++u) {
+        if (u * CH < NP) {
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            if (active[u]) {
+            for (int kt = 0; kt < NT; ++kt) {
+                SK_KEEP_ORDER();
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, p0u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ws_store(rwp, u, kt, e, f32_to_bf16(av[u][4] * p0[u][e] * b3[e]));
+                for (int ks = 0; ks < 2; ++ks) st = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[u][ks], st);
+                p0_from(st, kt, u, p0u);
+                const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
+                const float a4 = av[u][4];                                    // 0 for inactive tiles / padded queries
+                const u32x2_t pk = {pack_bf16x2(a4 * p0u[0] * b3[0], a4 * p0u[1] * b3[1]), pack_bf16x2(a4 * p0u[2] * b3[2], a4 * p0u[3] * b3[3])};
+                *reinterpret_cast<u32x2_t*>(chunk + chunk_wr + kt * 32) = pk;
             }
+            __syncthreads();
+            key_owner_products(dv, img1, u);
+            __syncthreads();
         }
-        SK_KEEP_ORDER();
+    }
+    store_key_rows(dv, 2);
+    }
+    SK_STAMP();           // 2: dV phase
+
+    // ---- G = dP7^T = V dO^T.  Every wave is past its dO reads: the dO slot takes Q now (three slots: lands during the walk)
+    // or V (two slots: Q follows at the end)
+    if (THREE) {
+        dma_image<NP, SKQ_WAVES>(img1, qbase, ldq, N, wave, lane);
+    } else {
+        dma_image<NP, SKQ_WAVES>(img1, qbase + 2 * p.H * DH, ldq, N, wave, lane);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        __syncthreads();
+    }
+    f32x4_t G[TPW][NT];             // fp32, walked back through the normalisations in place
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int qr = q[u] < N ? q[u] : N - 1;
+        bf16x8_t dof[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            SK_KEEP_ORDER();
+            G[u][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) G[u][kt] = mfma16(row_frag_img(vimg, kt * 16, ks, lane), dof[ks], G[u][kt]);
+        }
     }
 
-    // walk the normalisations backwards: steps 7 (row) 6 (col) 5 (row) 4 (col) 3 (row) 2 (col) 1 (row)
+    SK_STAMP();           // 3: V image + G
+    // ---- walk the normalisations backwards: steps 7 (row) 6 (col) 5 (row) 4 (col) 3 (row) 2 (col) 1 (row)
     // (fully unrolled: av[][] must be indexed statically or it lands in scratch)
 #pragma unroll
     for (int t = 3; t >= 0; --t) {
@@ -386,8 +498,10 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
             }
             __syncthreads();      // kap / colpart are rewritten by the next column step
         }
+        SK_STAMP();       // 4, 5, 6: row + column step
     }
-    // softmax backward: dS = P0 (G - sum_j G P0) * scale
+    SK_STAMP();           // 7: last row step
+    // ---- softmax backward: dS = P0 (G - sum_j G P0) * scale
     {
         float sd[TPW];
 #pragma unroll
@@ -417,27 +531,11 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
         }
     }
 
+    SK_STAMP();           // 8: softmax backward
+    // ---- dQ = dS K
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-        const int tile = wave + SKQ_WAVES * u;
-        if (!active[u] && tile < NT) {
-            // query columns nqt*16 .. NP-1 of the scratch are read (against zero Q / dO rows) by the key-owner kernel:
-            // make them finite
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ws_store(rwd, u, kt, e, 0);
-                    ws_store(rwp, u, kt, e, 0);
-                }
-        }
         if (active[u]) {
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                SK_KEEP_ORDER();
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ws_store(rwd, u, kt, e, f32_to_bf16(G[u][kt][e]));
-            }
             f32x4_t dq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -455,67 +553,34 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_q_k
             }
         }
     }
-}
 
-// ---------------------------------------------------------------------------------------------
-// backward, key-owner kernel: dK = dS^T Q, dV = P7^T dO  (dS^T, P7^T come from the scratch as [key][q] rows)
-// ---------------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(SKB_THREADS, 4) void sinkhorn_bwd_kv_kernel(const SinkParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* qimg = smem;
-    char* doimg = smem + NP * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const int N = p.N;
-    const long long ldq = 3ll * p.H * DH, ldo = (long long)p.H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
-    load_image<NP, false, SKB_THREADS>(qimg, qbase, ldq, N, tid);
-    load_image<NP, false, SKB_THREADS>(doimg, dobase, ldo, N, tid);
-    __syncthreads();
-    const bf16_t* wsp = p.ws_p + (long long)bh * NP * NP;
-    const bf16_t* wsd = p.ws_ds + (long long)bh * NP * NP;
-    const int g = lane >> 4, kc = lane & 15;
-    const int nkt = (N + 15) >> 4;
-    for (int kt = wave; kt < nkt; kt += SKB_THREADS / 64) {
-        const int key = kt * 16 + kc;          // < NP always: scratch rows exist (zero / garbage-free for key >= N? guarded below)
-        f32x4_t dk[4], dv[4];
+    SK_STAMP();           // 9: dQ
+    // ---- dK = dS^T Q  (two slots: Q replaces V now; the last V read was before the walk's barriers)
+    if (!THREE) dma_image<NP, SKQ_WAVES>(img1, qbase, ldq, N, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // this wave's part of the Q image; the barrier below publishes all parts
+    asm volatile("" ::: "memory");
+    f32x4_t dk[TPW][4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            dv[dt] = dk[dt];
-        }
-        const int kr = key < N ? key : N - 1;
-#pragma unroll 1
-        for (int qq = 0; qq < NP / 32; ++qq) {
-            // B operand: lane holds rows-of-scratch key, 8 consecutive queries 32 qq + 8 g ..  (natural k order;
-            // the matching A fragments below use the same natural order: rows 32 qq + 8 g + {0..7})
-            const bf16x8_t dsf = load_frag_global(wsd + (long long)kr * NP + qq * 32 + g * 8);
-            const bf16x8_t pf = load_frag_global(wsp + (long long)kr * NP + qq * 32 + g * 8);
+    for (int s = 0; s < TPW; ++s)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                // transposed A fragments with k = q in natural order: lane (g, i) needs rows 32 qq + 8 g + {0..7}
-                const int q4 = (lane & 15) >> 2, pp = lane & 3;
-                const int r0 = qq * 32 + 8 * g + q4;
-                const int c = 2 * dt + (pp >> 1);
-                const bf16x8_t qa = cat4(lds_read_tr16_b64(qimg + img_off(r0, c) + (pp & 1) * 8),
-                                         lds_read_tr16_b64(qimg + img_off(r0 + 4, c) + (pp & 1) * 8));
-                const bf16x8_t da = cat4(lds_read_tr16_b64(doimg + img_off(r0, c) + (pp & 1) * 8),
-                                         lds_read_tr16_b64(doimg + img_off(r0 + 4, c) + (pp & 1) * 8));
-                dk[dt] = mfma16(qa, dsf, dk[dt]);
-                dv[dt] = mfma16(da, pf, dv[dt]);
+        for (int dt = 0; dt < 4; ++dt) dk[s][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        if (u * CH < NP) {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const f32x4_t d = active[u] ? G[u][kt] : f32x4_t{0.f, 0.f, 0.f, 0.f};      // rows of absent tiles are read against zero Q rows: keep them finite
+                const u32x2_t pk = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+                *reinterpret_cast<u32x2_t*>(chunk + chunk_wr + kt * 32) = pk;
             }
-        }
-        if (key < N) {
-            bf16_t* dst = p.dqkv + ((long long)b * N + key) * ldq + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                store_bf16x4(dst + p.H * DH + dt * 16, dk[dt]);
-                store_bf16x4(dst + 2 * p.H * DH + dt * 16, dv[dt]);
-            }
+            __syncthreads();          // also orders the Q image stores (u == 0) before the transposed reads
+            key_owner_products(dk, img1, u);
+            __syncthreads();
         }
     }
+    store_key_rows(dk, 1);
+    SK_STAMP();           // 10: dK phase
+#undef SK_STAMP
 }
 
 int np_of(int N) { return (N + 31) / 32 * 32; }
@@ -534,17 +599,11 @@ int launch_sk_fwd(const SinkParams& p, hipStream_t s) {
 template <int NP>
 int launch_sk_bwd(const SinkParams& p, hipStream_t s) {
     constexpr int TPW = NRV_SK_TPW;
-    constexpr int lds_q = 2 * NP * 128 + (5 + 16 / TPW) * NP * 4;
-    constexpr int lds_kv = 2 * NP * 128;
-    static int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_q_kernel<NP, TPW>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    static int attr2 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_kv_kernel<NP>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    if (attr1 != 0) return attr1;
-    if (attr2 != 0) return attr2;
-    hipLaunchKernelGGL((sinkhorn_bwd_q_kernel<NP, TPW>), dim3(p.B * p.H), dim3(1024 / TPW), lds_q, s, p);
-    NRV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((sinkhorn_bwd_kv_kernel<NP>), dim3(p.B * p.H), dim3(SKB_THREADS), lds_kv, s, p);
+    constexpr int lds = SkBwdLds<NP, TPW>::BYTES;
+    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_kernel<NP, TPW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL((sinkhorn_bwd_kernel<NP, TPW>), dim3(p.B * p.H), dim3(1024 / TPW), lds, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }
@@ -583,28 +642,25 @@ extern "C" int nrv_attn_sinkhorn_fwd(const void* qkv_bf16, void* out_bf16, float
     NRV_SK_DISPATCH(N, launch_sk_fwd<NPV>(p, s));
 }
 
-extern "C" size_t nrv_attn_sinkhorn_bwd_workspace(int B, int N, int H) {
-    if (B <= 0 || N <= 0 || H <= 0) return 0;
-    const size_t np = (size_t)np_of(N);
-    return 2 * (size_t)B * H * np * np * 2;
-}
+#ifdef NRV_SK_STAMPS
+static unsigned long long* g_sk_stamps = nullptr;
+extern "C" void nrv_dev_sinkhorn_stamp_buffer(void* p) { g_sk_stamps = static_cast<unsigned long long*>(p); }
+#endif
 
 extern "C" int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16, const float* lse, const float* scalings,
-                                     void* dqkv_bf16, void* workspace, size_t workspace_bytes,
-                                     int B, int N, int H, int dh, float scale, void* stream) {
-    if (!qkv_bf16 || !dout_bf16 || !lse || !scalings || !dqkv_bf16 || !workspace) return NRV_ERR_NULL;
+                                     void* dqkv_bf16, int B, int N, int H, int dh, float scale, void* stream) {
+    if (!qkv_bf16 || !dout_bf16 || !lse || !scalings || !dqkv_bf16) return NRV_ERR_NULL;
     if (int e = sk_check(B, N, H, dh)) return e;
-    if (!nrv_aligned16(qkv_bf16) || !nrv_aligned16(dout_bf16) || !nrv_aligned16(dqkv_bf16) || !nrv_aligned16(workspace)) return NRV_ERR_ALIGN;
-    const size_t np = (size_t)np_of(N);
-    const size_t half = (size_t)B * H * np * np * 2;
-    if (workspace_bytes < 2 * half) return NRV_ERR_WORKSPACE;
+    if (!nrv_aligned16(qkv_bf16) || !nrv_aligned16(dout_bf16) || !nrv_aligned16(dqkv_bf16)) return NRV_ERR_ALIGN;
     SinkParams p{};
     p.qkv = static_cast<const bf16_t*>(qkv_bf16);
     p.dout = static_cast<const bf16_t*>(dout_bf16);
     p.dqkv = static_cast<bf16_t*>(dqkv_bf16);
     p.lse = const_cast<float*>(lse); p.scal = const_cast<float*>(scalings);
-    p.ws_ds = static_cast<bf16_t*>(workspace);
-    p.ws_p = reinterpret_cast<bf16_t*>(static_cast<char*>(workspace) + half);
+#ifdef NRV_SK_STAMPS
+    if (!g_sk_stamps) return NRV_ERR_NULL;
+    p.stamps = g_sk_stamps;
+#endif
     p.B = B; p.N = N; p.H = H; p.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     NRV_SK_DISPATCH(N, launch_sk_bwd<NPV>(p, s));

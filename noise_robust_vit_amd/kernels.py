@@ -310,10 +310,9 @@ def attn_sinkhorn_bwd(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: i
         raise NrvError("attn_sinkhorn_bwd: operands must be contiguous")
     dqkv = torch.empty_like(qkv)
     lib = _lib.load()
-    ws = _workspace(lib.nrv_attn_sinkhorn_bwd_workspace(B, N, H), qkv.device)
-    _run("attn_sinkhorn_bwd", 10.0 * B * H * N * N * dh, 2 * B * N * H * dh * 7 + 2 * ws.numel(),
+    _run("attn_sinkhorn_bwd", 10.0 * B * H * N * N * dh, 2 * B * N * H * dh * 7,
          lambda: lib.nrv_attn_sinkhorn_bwd(qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), scal.data_ptr(), dqkv.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), B, N, H, dh, float(scale), _stream()),
+                                           B, N, H, dh, float(scale), _stream()),
          "nrv_attn_sinkhorn_bwd")
     return dqkv
 
