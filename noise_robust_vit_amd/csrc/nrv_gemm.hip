@@ -663,7 +663,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     };
     constexpr int ND = C::CA + C::CB;
     constexpr int NG = C::MI, GH = C::MI / 2;            // MFMA groups per K-tile: 2 k-steps x MI/2 row-block pairs
-    constexpr int NGD = 4 < NG ? 4 : NG;                 // groups that carry the next tile's DMA issue
+    constexpr int NGD = NRV_DMA_GROUPS < NG ? NRV_DMA_GROUPS : NG;      // groups that carry the next tile's DMA issue
 
     // transposed fragment read offsets: lane (g = l>>4, q = (l&15)>>2, pp = l&3) supplies row 4g+q (+16 r + 32 ks);
     // one offset register per 16-column block of the wave (its unit index is not a multiple of 8 in every configuration,

@@ -139,8 +139,34 @@ def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
     return None, 0.0
 
 
+def sink_params(params) -> list:
+    """The registered parameters behind a layer's tensors: a fused projection (`_nrv_parts`, lucid_vit.Attention) stands for
+    the parameters whose rows it stacks."""
+    out = []
+    for q in params:
+        if q is None:
+            continue
+        parts = getattr(q, "_nrv_parts", None)
+        out += [pp for pp, _, _ in parts] if parts is not None else [q]
+    return out
+
+
 def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
     """Weight and bias gradient of y = x W^T + b in ONE kernel: dW = dy^T x on the MFMA, db = colsum(dy) fused."""
+    parts = getattr(w, "_nrv_parts", None)
+    if parts is not None and meta.sink is not None:
+        # w stacks the rows of several parameters ([to_q; to_kv]): one TN GEMM per parameter on the matching column block of
+        # dy, straight into that parameter's slot of the sink (no fused gradient, no split / accumulate pass)
+        if b is not None:
+            raise NrvError("a fused projection carries no bias")
+        block = meta.sink.target_block([pp for pp, _, _ in parts]) if hasattr(meta.sink, "target_block") else None
+        if block is not None:                    # the parameters' slots are adjacent (GradReducer + grad_groups): one GEMM
+            K.gemm_tn(dy16, x16, out=block[0], beta=block[1])
+            return None, None
+        for pp, r0, r1 in parts:
+            tw, bw = meta.sink.target(pp)
+            K.gemm_tn(dy16[:, r0:r1], x16, out=tw, beta=bw)
+        return None, None
     tw, bw = _grad_target(meta, w)
     tb, bb = _grad_target(meta, b) if b is not None else (None, 0.0)
 
@@ -347,7 +373,7 @@ class EncoderStackFn(torch.autograd.Function):
             grads[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = ga + gm
             saved[i] = None                                  # free this block's activations early
             if meta.sink is not None:
-                meta.sink.layer_done(i, [q for q in p if q is not None])
+                meta.sink.layer_done(i, sink_params(p))
         grads = _mask_sink_grads(meta, grads)
         return (d32.reshape(B, N, D), None, *grads)
 

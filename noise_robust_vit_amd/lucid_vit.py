@@ -78,11 +78,25 @@ class Attention(nn.Module):
         WEIGHTS.add_derived(self._refresh_fused)
 
     def _refresh_fused(self):
-        """Keep the fused projection current: rebuilt (two row-block copies, in place) only when a source changed --
-        version counters / addresses, or the weight cache's epoch for updates through raw pointers (optim.FusedAdamW)."""
+        """The fused projection [to_q.weight; to_kv.weight] as ONE fp32 tensor.
+        * optim.FusedAdamW keeps the parameters in a flat buffer with the gradient slots' layout, and grad_groups() puts to_q /
+          to_kv back to back there: the fused projection is then simply a VIEW of that memory -- no copy, never stale;
+        * otherwise a persistent buffer, rebuilt (two row-block copies, in place) only when a source changed -- version
+          counters / addresses, or the weight cache's epoch for updates through raw pointers."""
         wq, wkv = self.to_q.weight, self.to_kv.weight
+        adjacent = (wq.is_contiguous() and wkv.is_contiguous() and wq.dtype == torch.float32 and wkv.dtype == torch.float32
+                    and wq.untyped_storage().data_ptr() == wkv.untyped_storage().data_ptr()
+                    and wkv.data_ptr() == wq.data_ptr() + wq.numel() * 4)
+        if adjacent:
+            key = ("view", wq.data_ptr(), wkv.data_ptr())
+            if self._fused_key != key:
+                # a tensor of its own over the same storage (not a view with a `_base`: the weight cache tracks owners)
+                self._fused = torch.empty(0, dtype=torch.float32, device=wq.device).set_(
+                    wq.untyped_storage(), wq.storage_offset(), (wq.shape[0] + wkv.shape[0], wq.shape[1]), (wq.shape[1], 1))
+                self._fused_key = key
+            return self._fused
         key = (wq._version, wkv._version, wq.data_ptr(), wkv.data_ptr(), WEIGHTS.epoch)
-        if self._fused is None or self._fused.device != wq.device:
+        if self._fused is None or self._fused.device != wq.device or (isinstance(self._fused_key, tuple) and self._fused_key[:1] == ("view",)):
             self._fused = torch.empty(wq.shape[0] + wkv.shape[0], wq.shape[1], dtype=torch.float32, device=wq.device)
             self._fused_key = None
         if self._fused_key != key:
@@ -92,11 +106,17 @@ class Attention(nn.Module):
             self._fused_key = key
         return self._fused
 
-    def layer_params(self):
+    def layer_params(self, for_sink: bool = False):
         # one [3*inner, dim] projection for the fused QKV GEMM: a persistent buffer whose bf16 images stay cached across
-        # forwards (a fresh torch.cat per call would be re-cast and re-transposed every time); _FusedRowsFn hands the
-        # gradient rows back to to_q / to_kv
-        wqkv = _FusedRowsFn.apply(self, self.to_q.weight, self.to_kv.weight)
+        # forwards (a fresh torch.cat per call would be re-cast and re-transposed every time).  Under autograd _FusedRowsFn
+        # hands the gradient rows back to to_q / to_kv; with a gradient sink (parallel.GradReducer) the buffer itself is
+        # passed, tagged with the parameters whose rows it stacks: the backward writes each block into its slot directly
+        if for_sink:
+            wqkv = self._refresh_fused()
+            rows = self.to_q.weight.shape[0]
+            wqkv._nrv_parts = [(self.to_q.weight, 0, rows), (self.to_kv.weight, rows, wqkv.shape[0])]
+        else:
+            wqkv = _FusedRowsFn.apply(self, self.to_q.weight, self.to_kv.weight)
         return [self.norm.weight, self.norm.bias, wqkv, None, self.to_out[0].weight, self.to_out[0].bias]
 
     def forward(self, x, attn_mask=None, memories=None):
@@ -115,13 +135,25 @@ class Transformer(nn.Module):
         self.p = dropout
         self._meta = BlockMeta(heads=heads, dim_head=dim_head, eps=1e-5)
 
+    def grad_groups(self):
+        """Parameters whose gradients one kernel writes as consecutive row blocks: parallel.GradReducer lays their slots out
+        back to back in this order."""
+        return [(attn.to_q.weight, attn.to_kv.weight) for attn, _ in self.layers]
+
+    def attach_grad_sink(self, sink) -> None:
+        """The layers' weight gradients go straight into the sink's flat buffer (parallel.GradReducer), as in
+        simple_vit.Transformer / vit.Encoder: no per-parameter fill + accumulate pass through autograd."""
+        self._meta.sink = sink
+
     def forward(self, x, attn_mask=None, memories=None):
         if attn_mask is not None or memories is not None:
             raise NotImplementedError("attention masks / memory tokens are outside the encoder hot path")
         _no_dropout(self.p if self.training else 0.0)
+        # a sink only receives gradients of a training step: under no_grad (evaluation) nothing is written anyway
+        for_sink = self._meta.sink is not None
         flat = []
         for attn, ff in self.layers:
-            flat += attn.layer_params() + ff.layer_params()
+            flat += attn.layer_params(for_sink) + ff.layer_params()
         return EncoderStackFn.apply(x, self._meta, *flat)
 
 
@@ -143,6 +175,12 @@ class ViT(nn.Module):
         self.dropout = nn.Dropout(emb_dropout)
         self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
         self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
+
+    def grad_groups(self):
+        return self.transformer.grad_groups()
+
+    def attach_grad_sink(self, sink) -> None:
+        self.transformer.attach_grad_sink(sink)
 
     def img_to_tokens(self, img):
         _no_dropout(self.dropout.p if self.training else 0.0)

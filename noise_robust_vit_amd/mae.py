@@ -44,6 +44,14 @@ class MAE(nn.Module):
         self.decoder_pos_emb = nn.Embedding(n_patches, decoder_dim)
         self.to_pixels = nn.Linear(decoder_dim, pixels)
 
+    def grad_groups(self):
+        return self.encoder.transformer.grad_groups() + self.decoder.grad_groups()
+
+    def attach_grad_sink(self, sink) -> None:
+        """Both transformers write their weight gradients into the data-parallel runtime's flat buffer directly."""
+        self.encoder.transformer.attach_grad_sink(sink)
+        self.decoder.attach_grad_sink(sink)
+
     # -- helpers ----------------------------------------------------------------------------------------------------
     def _embed_all(self, img: torch.Tensor, n: int) -> torch.Tensor:
         """tokens[b, t] = patch_to_emb(patch) + pos_embedding[1 + t]  -- one GEMM, positions in its epilogue (mae.py:61-62)."""

@@ -47,8 +47,21 @@ class GradReducer:
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
                     dist.broadcast(t.data, src=0, group=process_group)
-        # backward order: the reverse of registration order (head ... first encoder layer ... patch embed)
+        # backward order: the reverse of registration order (head ... first encoder layer ... patch embed); parameters the
+        # model wants back to back in a given order (`grad_groups()`: lucid_vit's to_q / to_kv, whose gradients are the row
+        # blocks of ONE fused-projection GEMM) are placed as a unit where the first of them falls
         order = list(reversed(params))
+        groups = [tuple(g) for g in model.grad_groups()] if hasattr(model, "grad_groups") else []
+        if groups:
+            group_of = {id(q): g for g in groups for q in g}
+            placed, regrouped = set(), []
+            for q in order:
+                if id(q) in placed:
+                    continue
+                for m in group_of.get(id(q), (q,)):
+                    regrouped.append(m)
+                    placed.add(id(m))
+            order = regrouped
         dev = params[0].device
         sizes = [p.numel() for p in order]
         # 16-byte aligned slots so every view can be a kernel output
@@ -107,6 +120,20 @@ class GradReducer:
         """Where a kernel should write d(loss)/d(p) this step, and the beta to use (0: overwrite)."""
         self._sink_managed.add(id(p))
         return self._views[id(p)], 0.0
+
+    def target_block(self, params: Sequence[torch.Tensor]):
+        """One [sum of rows, cols] view over the slots of `params` when they lie back to back in this order (grad_groups),
+        and the beta to use; None otherwise (the caller then writes each parameter's block separately)."""
+        start, _ = self._slot[id(params[0])]
+        end = start
+        for q in params:
+            o, n = self._slot[id(q)]
+            if o != end or n % 4 or q.dim() != 2 or q.shape[1] != params[0].shape[1]:
+                return None
+            end = o + n
+        for q in params:
+            self._sink_managed.add(id(q))
+        return self.flat[start:end].view(-1, params[0].shape[1]), 0.0
 
     def layer_done(self, layer_index: int, params: Sequence[torch.Tensor]) -> None:
         for p in params:

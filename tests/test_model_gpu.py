@@ -452,6 +452,92 @@ def test_mae_vit_b_geometry_49_tokens_against_oracle(dev):
     print("worst grad rel-L2:", worst)
 
 
+def test_mae_gradients_through_the_reducer_sink_match_autograd(dev):
+    """With a GradReducer attached (every training step: train.Trainer builds one even on a single GPU) both MAE transformers
+    write their weight gradients into the flat buffer directly -- the fused [to_q; to_kv] projection as one TN GEMM per
+    parameter on its column block of dQKV.  Same loss and the same gradients as the plain autograd run (bit-equal up to the
+    summation order of the split-K slabs), every parameter with a gradient reported as ready, and a second step overwrites
+    rather than accumulates."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd.mae import MAE
+    from noise_robust_vit_amd.parallel import GradReducer
+    torch.manual_seed(3)
+    enc = ViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256)
+    mae = MAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, decoder_dim_head=64).to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(4, 3, 64, 64, generator=g).to(dev)
+    idx = torch.rand(4, 16, generator=g).argsort(dim=-1).to(dev)
+    loss0 = mae(img, rand_indices=idx)
+    loss0.backward()
+    ref = {k: p.grad.detach().clone() for k, p in mae.named_parameters() if p.grad is not None}
+    for p in mae.parameters():
+        p.grad = None
+    red = GradReducer(mae, 1)
+    assert mae.encoder.transformer._meta.sink is red and mae.decoder._meta.sink is red
+    a0 = mae.encoder.transformer.layers[0][0]              # to_q / to_kv slots back to back: one dWqkv GEMM writes both
+    assert red.slot(a0.to_kv.weight)[0] == sum(red.slot(a0.to_q.weight)) and red.target_block([a0.to_q.weight, a0.to_kv.weight]) is not None
+    for step in range(2):                                   # the second pass must overwrite, not accumulate
+        red.begin_step()
+        loss = mae(img, rand_indices=idx)
+        loss.backward()
+        red.finish_step()
+        assert abs(loss.item() - loss0.item()) < 1e-6 * max(1.0, abs(loss0.item()))
+        for k, p in mae.named_parameters():
+            if k not in ref:
+                continue
+            assert p.grad is not None and p.grad.data_ptr() == red._views[id(p)].data_ptr(), k     # still the flat-buffer view
+            rel = ((p.grad - ref[k]).norm() / ref[k].norm().clamp_min(1e-30)).item()
+            assert rel < 2e-6, (step, k, rel)
+        missing = {id(p) for p in red.params_without_grad()}
+        got_grad = {id(p) for k, p in mae.named_parameters() if k in ref}
+        assert not (missing & got_grad)
+    # evaluation with the sink attached: nothing is written, nothing breaks
+    with torch.no_grad():
+        mae.eval()
+        assert torch.isfinite(mae(img, rand_indices=idx))
+
+
+def test_mae_trainer_steps_with_fused_projection_as_a_view_of_the_flat_parameters(dev):
+    """train.Trainer on the MAE wrapper: FusedAdamW keeps the parameters in a flat buffer with the gradient slots' layout,
+    so [to_q.weight; to_kv.weight] is a zero-copy view of it (no per-step row-block copies) and its bf16 images follow the
+    raw-pointer AdamW updates.  Three steps must give the losses of the same model trained WITHOUT the reducer sink and
+    without FusedAdamW's layout: plain autograd + torch.optim.AdamW on a CPU-initialised twin, same inputs and mask."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd.mae import MAE
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+
+    def make():
+        torch.manual_seed(11)
+        enc = ViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256)
+        return MAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, decoder_dim_head=64).to(dev).train()
+
+    g = torch.Generator().manual_seed(6)
+    img = torch.randn(4, 3, 64, 64, generator=g).to(dev)
+    idx = torch.rand(4, 16, generator=g).argsort(dim=-1).to(dev)
+    a, b = make(), make()
+    tr = Trainer(a, TrainConfig(lr=1e-2, weight_decay=0.05, grad_max_norm=0.0), None, compute_loss=lambda m, x, y: m(x, rand_indices=idx))
+    att = a.encoder.transformer.layers[0][0]
+    fused = att._refresh_fused()
+    assert fused.data_ptr() == att.to_q.weight.data_ptr() and fused._base is None          # the view, not a copy
+    assert torch.equal(fused[att.to_q.weight.shape[0]:], att.to_kv.weight.detach())
+    opt = torch.optim.AdamW(b.parameters(), lr=1e-2, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999))
+    for step in range(3):
+        la = tr.step(img, None).item()
+        opt.zero_grad(set_to_none=True)
+        lb = b(img, rand_indices=idx)
+        lb.backward()
+        opt.step()
+        from noise_robust_vit_amd.encoder import WEIGHTS
+        WEIGHTS.clear()                                     # torch's fused AdamW may not bump version counters (train.py)
+        assert abs(la - lb.item()) < 2e-3 * abs(lb.item()), (step, la, lb.item())
+    assert att._refresh_fused().data_ptr() == att.to_q.weight.data_ptr()
+    for (ka, pa), (kb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pb.grad is None:
+            continue
+        rel = ((pa.detach() - pb.detach()).norm() / pb.detach().norm().clamp_min(1e-30)).item()
+        assert rel < 2e-2, (ka, rel)          # three AdamW steps at lr 1e-2: sign-like updates amplify bf16-level gradient noise
+
+
 def test_lucid_fused_qkv_images_are_cached_and_follow_updates(dev):
     """lucid_vit.Attention feeds the fused QKV GEMM from a persistent [to_q; to_kv] buffer: no cast_transpose per forward
     once staged, and an in-place parameter update (version bump) or a raw-pointer update (FusedAdamW -> refresh_all) is
