@@ -204,3 +204,31 @@ def test_trainer_on_cpu_uses_torch_adamw_and_fused_optimizer_refuses_cpu():
     assert red.parameters() and red.slot(red.parameters()[0])[1] == 12
     with pytest.raises(NrvError):
         FusedAdamW(red, lr=1e-3)
+
+
+def test_grad_reducer_places_grouped_parameters_back_to_back():
+    """`grad_groups()` (lucid_vit: to_q / to_kv, whose gradients are the row blocks of one fused-projection GEMM): the
+    reducer lays the group's slots out consecutively in the group's order, `target_block` hands out ONE view over them,
+    every other parameter keeps backward order, and an MAE / lucid model exposes one group per attention layer."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd.mae import MAE
+    from noise_robust_vit_amd.parallel import GradReducer
+    enc = ViT(image_size=32, patch_size=16, num_classes=4, dim=64, depth=2, heads=1, mlp_dim=128)
+    mae = MAE(encoder=enc, decoder_dim=64, decoder_depth=1, decoder_heads=1, decoder_dim_head=64)
+    groups = mae.grad_groups()
+    assert len(groups) == 3 and all(len(g) == 2 for g in groups)
+    red = GradReducer(mae, 1, attach=False)
+    used = 0
+    for q, kv in groups:
+        (oq, nq), (okv, nkv) = red.slot(q), red.slot(kv)
+        assert okv == oq + nq                                  # to_kv directly behind to_q
+        blk = red.target_block([q, kv])
+        assert blk is not None and blk[0].shape == (q.shape[0] + kv.shape[0], q.shape[1]) and blk[1] == 0.0
+        assert blk[0].data_ptr() == q.grad.data_ptr()
+        used += 1
+    assert red.target_block([groups[0][1], groups[0][0]]) is None          # wrong order: not one block
+    # slots tile the flat buffer without overlap
+    spans = sorted(red.slot(p) for p in red.parameters())
+    for (o0, n0), (o1, _) in zip(spans, spans[1:]):
+        assert o0 + (n0 + 3) // 4 * 4 == o1
+    assert spans[-1][0] + (spans[-1][1] + 3) // 4 * 4 == red.flat.numel()
