@@ -137,6 +137,9 @@ VT_CASES = {
     # ViT-B/16 geometry (BASELINE.json configs[2], the headline): 12 heads, D 768, M 3072, 197 tokens; 2 of its 12 layers
     "vit_b_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=13), 2,
                     1.0e-2, 6.5e-3, 1.6e-2),       # measured 4.9e-3, 3.2e-3, 8.0e-3
+    # the headline model itself: vit_b_16 as bench.py builds it (12 layers, 1000 classes), batch 2
+    "vit_b_16_full": (dict(image_size=224, patch_size=16, num_layers=12, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=1000), 2,
+                      1.1e-2, 8.5e-3, 1.9e-2),     # measured 5.8e-3, 4.4e-3 (emulating vs fp32 oracle: 5.2e-3), 9.9e-3 (conv_proj.weight); loss 6.6949 vs 6.6962
     # ViT-L/16 geometry (BASELINE.json configs[3]): 16 heads, D 1024, M 4096, 197 tokens; 2 of its 24 layers
     "vit_l_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=11), 2,
                     1.0e-2, 1.1e-2, 1.6e-2),       # measured 4.7e-3, 5.5e-3 (the emulating oracle itself is 4.7e-3 from the fp32 one), 7.9e-3
