@@ -143,7 +143,12 @@ VT_CASES = {
     # ViT-L/16 geometry (BASELINE.json configs[3]): 16 heads, D 1024, M 4096, 197 tokens; 2 of its 24 layers
     "vit_l_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=11), 2,
                     1.0e-2, 1.1e-2, 1.6e-2),       # measured 4.7e-3, 5.5e-3 (the emulating oracle itself is 4.7e-3 from the fp32 one), 7.9e-3
+    # the full vit_l_16 of the bench (24 layers, 1000 classes), batch 1
+    "vit_l_16_full": (dict(image_size=224, patch_size=16, num_layers=24, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=1000), 1,
+                      9.7e-3, 7.2e-3, 2.0e-2),     # measured 4.9e-3, 3.6e-3 (emulating vs fp32 oracle: 4.4e-3), 1.04e-2 (layer 0 ln_1.weight); loss 5.9773 vs 5.9798
 }
+# loss bound per case where 24 layers of bf16 operand rounding exceed the default (measured 2.5e-3 on vit_l_16_full)
+VT_LOSS_BOUNDS = {"vit_l_16_full": 5e-3}
 
 
 def _vt_setup(cfg, B, dev):
@@ -187,7 +192,7 @@ def test_vision_transformer_against_oracle(dev, case):
     print(f"VT {case}: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e} (emulating vs fp32 oracle {e_oo:.3e}), "
           f"loss {loss.item():.6f} vs {ref_loss.item():.6f}, worst grad rel-L2 {worst[0]:.3e} ({worst[1]})")
     assert e_ref < tol_ref and e_emu < tol_emu
-    assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
+    assert abs(loss.item() - ref_loss.item()) < VT_LOSS_BOUNDS.get(case, LOSS_TOL_FP32REF)
 
 
 @pytest.mark.parametrize("case", ["d192_l2_n5", "vit_b_16_l2"])
