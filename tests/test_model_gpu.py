@@ -195,6 +195,44 @@ def test_vision_transformer_against_oracle(dev, case):
     assert abs(loss.item() - ref_loss.item()) < VT_LOSS_BOUNDS.get(case, LOSS_TOL_FP32REF)
 
 
+def test_vision_transformer_robust_vit_b_geometry_against_oracle(dev):
+    """robust=True (Sinkhorn attention, utils.py:1031-1037) at the ViT-B/16 geometry -- 12 heads, 197 tokens, 2 layers: logits,
+    loss and EVERY parameter gradient against the CPU oracle.  The backward of every head runs the one-kernel Sinkhorn
+    backward at NP = 224 (three LDS image slots, transposition chunk of 128 queries)."""
+    from noise_robust_vit_amd import VisionTransformer
+    from oracle import vit_oracle as V
+    from oracle.simple_vit_oracle import cross_entropy_ls
+    cfg = dict(image_size=224, patch_size=16, num_layers=2, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=13)
+    sd = V.vit_init_state_dict(seed=3, **cfg)
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        if k.endswith("bias") or k == "class_token":
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    model = VisionTransformer(**cfg, robust=True)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    x = torch.randn(2, 3, 224, 224, generator=g)
+    y = torch.randint(0, 13, (2,), generator=g)
+    logits = model(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.1)
+    loss.backward()
+    torch.set_num_threads(8)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = V.vit_forward(leaves, x, patch_size=16, num_heads=12, robust=True)
+    ref_loss = cross_entropy_ls(ref, y)
+    ref_loss.backward()
+    emu = V.vit_forward(sd, x, patch_size=16, num_heads=12, robust=True, emulate_bf16=True)
+    e_ref, e_emu = relmax(logits, ref), relmax(logits, emu)
+    worst = check_grads(model, {k: v.grad for k, v in leaves.items()}, tol=ROBUST_VT_BOUNDS[2])
+    print(f"VT robust vit_b_16_l2: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}, "
+          f"loss {loss.item():.6f} vs {ref_loss.item():.6f}, worst grad rel-L2 {worst[0]:.3e} ({worst[1]})")
+    assert e_ref < ROBUST_VT_BOUNDS[0] and e_emu < ROBUST_VT_BOUNDS[1]
+    assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
+
+
+ROBUST_VT_BOUNDS = (1.0e-2, 6.4e-3, 1.5e-2)      # measured on MI355X: 5.0e-3, 3.2e-3, 7.7e-3 (conv_proj.weight); loss 2.48822 vs 2.48793
+
+
 @pytest.mark.parametrize("case", ["d192_l2_n5", "vit_b_16_l2"])
 def test_vision_transformer_stage_localisation(dev, case):
     """Where do kernel and bf16-emulating oracle part ways?  Per stage (patch embedding, every attention / MLP half):
