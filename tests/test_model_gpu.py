@@ -143,12 +143,15 @@ VT_CASES = {
     # ViT-L/16 geometry (BASELINE.json configs[3]): 16 heads, D 1024, M 4096, 197 tokens; 2 of its 24 layers
     "vit_l_16_l2": (dict(image_size=224, patch_size=16, num_layers=2, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=11), 2,
                     1.0e-2, 1.1e-2, 1.6e-2),       # measured 4.7e-3, 5.5e-3 (the emulating oracle itself is 4.7e-3 from the fp32 one), 7.9e-3
+    # the full vit_s_16 of the bench (configs[1]: D 384, 6 heads, M 1536, 12 layers; N = 384 runs the 384 x 128 NT tile), batch 2
+    "vit_s_16_full": (dict(image_size=224, patch_size=16, num_layers=12, num_heads=6, hidden_dim=384, mlp_dim=1536, num_classes=1000), 2,
+                      1.0e-2, 8.8e-3, 2.2e-2),     # measured 5.3e-3, 4.4e-3 (emulating vs fp32 oracle: 5.2e-3), 1.13e-2 (layer 0 ln_1.weight); loss 7.1418 vs 7.1446
     # the full vit_l_16 of the bench (24 layers, 1000 classes), batch 1
     "vit_l_16_full": (dict(image_size=224, patch_size=16, num_layers=24, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=1000), 1,
                       9.7e-3, 7.2e-3, 2.0e-2),     # measured 4.9e-3, 3.6e-3 (emulating vs fp32 oracle: 4.4e-3), 1.04e-2 (layer 0 ln_1.weight); loss 5.9773 vs 5.9798
 }
 # loss bound per case where 24 layers of bf16 operand rounding exceed the default (measured 2.5e-3 on vit_l_16_full)
-VT_LOSS_BOUNDS = {"vit_l_16_full": 5e-3}
+VT_LOSS_BOUNDS = {"vit_l_16_full": 5e-3, "vit_s_16_full": 5.7e-3}      # measured 2.5e-3, 2.9e-3
 
 
 def _vt_setup(cfg, B, dev):
