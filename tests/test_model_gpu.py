@@ -235,7 +235,8 @@ def test_full_model_loss_deviation_is_rounding_noise_not_bias(dev, name, cfg):
     assert abs(mean_off) < max(abs(r[2]) for r in rows), (mean_off, rows)
 
 
-def test_full_size_properties_batch_256_vit_b_16(dev):
+@pytest.mark.parametrize("robust", [False, True])
+def test_full_size_properties_batch_256_vit_b_16(dev, robust):
     """BASELINE.json configs[2] at its FULL size (vit_b_16, batch 256: 50 432 token rows per GEMM, too large for the CPU oracle)
     through size-independent properties:
       * determinism: the same forward + backward twice gives bit-identical logits and gradients (no atomics anywhere);
@@ -247,7 +248,7 @@ def test_full_size_properties_batch_256_vit_b_16(dev):
     from noise_robust_vit_amd import VisionTransformer
     torch.manual_seed(0)
     cfg = dict(image_size=224, patch_size=16, num_layers=12, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=1000)
-    model = VisionTransformer(**cfg)
+    model = VisionTransformer(**cfg, robust=robust)          # robust: Sinkhorn attention, one-kernel backward per head
     with torch.no_grad():
         model.heads.head.weight.normal_(0.0, 0.02)           # the reference zero-initialises the head (vit.py:304-306)
     model = model.to(dev).train()
@@ -292,7 +293,7 @@ def test_full_size_properties_batch_256_vit_b_16(dev):
         # not fp32-summation-order small: the torch head's logits differ in the last fp32 bits between row counts (above), which
         # flips bf16 roundings of the residual-stream gradient here and there -- the same noise as against the oracle
         assert rel < 2e-2, (k, rel)
-    print(f"full size vit_b_16 batch 256: deterministic, sample-independent (bit-equal); "
+    print(f"full size vit_b_16 batch 256 robust={robust}: deterministic, sample-independent (bit-equal); "
           f"grad(256) vs mean of two half-batch grads: worst rel-L2 {worst[0]:.2e} ({worst[1]})")
 
 
