@@ -157,6 +157,17 @@ __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, void* lds_ba
 #endif
 }
 
+// the same, LDS destination given as a (wave-uniform) LDS byte address: no generic-pointer cast per instruction
+__device__ __forceinline__ void dma16s_at(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %1, %3 offen lds"
+        :
+        : "v"(voffset), "s"(rsrc), "s"(lds_addr), "s"(soffset)
+        : "memory", "m0");
+}
+
 __device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {
     return *reinterpret_cast<const bf16x8_t*>(p);
 }

@@ -20,6 +20,7 @@
 // Reference call sites replaced: simple_vit.py:39,41,61,62,130 ; vit.py:40-47 ; utils.py:115,579.
 
 #include "nrv_common.hpp"
+#include <type_traits>
 
 #ifndef NRV_DMA_GROUPS
 #define NRV_DMA_GROUPS 4
@@ -563,6 +564,217 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT kernel, phased main loop (cdna_hip_programming.md "The 256^2 8-phase template", T3 + T4 + T5): the same output
+// tile, wave layout, swizzle and epilogues as gemm_nt_kernel, another K loop.
+//
+//   * Each operand tile of a K-step is staged as two HALF-tiles: A half h = the rows (16 MI) wr + 8 MI h + [0, 8 MI) of both
+//     wave rows, B half h = the columns 64 wc + 32 h + [0, 32) of the four wave columns, so that every wave owns one
+//     quadrant (A half i) x (B half j) of its block per PHASE.  A K-step is four phases:
+//         phase 0: read B0, A0 | quadrant (A0, B0)      phase 2: read A1 | quadrant (A1, B1)
+//         phase 1: read B1     | quadrant (A0, B1)      phase 3: --      | quadrant (A1, B0)   (B0 stays in registers)
+//     each phase = [fragment reads + ONE half-tile of LDS-DMA + counted vmcnt] s_barrier [MFMAs under s_setprio 1] s_barrier.
+//   * Waves 4-7 (wave row 1; the SIMD partners of waves 0-3) run ONE barrier behind waves 0-3: on every SIMD one wave is in
+//     its MFMA section while the other reads fragments and issues DMA.
+//   * Half-tile op n = 4 t + {A0, B0, B1, A1} of K-step t is issued in global phase n - 6 (a half is re-staged >= 2 phases
+//     after its last fragment read in either wave group) and first read in phase >= n - 1: five phases (2.5 K-step
+//     quarters) of flight.  The wait in phase g - 1 for what phase g reads leaves the four youngest ops (one of each
+//     kind) in flight: ONE counted vmcnt value for the whole loop, never 0 before the last K-step.  RAW: every wave's
+//     counted wait precedes a barrier that every reader passes before its read (also across the stagger).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
+__global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTParams p) {
+    static_assert(C::WM == 2 && C::WN == 4 && C::NI == 4 && C::MI % 2 == 0, "2 x 4 waves, 64-column wave blocks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MH = C::MI / 2;                                   // row tiles per wave and half
+    constexpr int AH = C::TBM / 2 * 128, BH = C::TBN / 2 * 128;     // bytes of a half-tile image (128-byte rows)
+    constexpr int STG = 2 * AH + 2 * BH;
+    constexpr int PA = AH / 1024, PB = BH / 1024;                   // 1-KiB DMA pieces (8 rows) per half
+    static_assert(PB % 8 == 0 && PA % 4 == 0, "pieces divide over the waves");
+    // pieces of an A half per wave: PA / 8, the remainder (MI = 10: 4 pieces) goes to waves 0-3 in half 0 and to waves 4-7
+    // in half 1, so that every wave issues the same number per K-step and per window of four consecutive ops
+    constexpr int NA = (PA + 7) / 8, NB = PB / 8;
+    constexpr bool A_UNEVEN = (PA % 8) != 0;
+    constexpr int W4 = (A_UNEVEN ? 2 * NA - 1 : 2 * NA) + 2 * NB;   // DMA instructions of four consecutive ops (one per kind)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    if (p.gn > 0 && p.tiles_n > p.gn) {
+        const int tiles_m = gridDim.x / p.tiles_n;
+        const int gsize = tiles_m * p.gn;
+        const int grp = id / gsize, within = id - grp * gsize;
+        const int gw = (grp + 1) * p.gn <= p.tiles_n ? p.gn : p.tiles_n - grp * p.gn;
+        tm = within / gw;
+        tn = grp * p.gn + (within - tm * gw);
+    } else {
+        tm = id / p.tiles_n;
+        tn = id - tm * p.tiles_n;
+    }
+    const int m0 = tm * C::TBM, n0 = tn * C::TBN;
+    const int M = p.e.M, N = p.e.N;
+    const int nk = p.K / BK;                                        // host: K % 64 == 0, nk >= 3
+
+    // rows >= M - m0 / >= N - n0 lie behind the records and read as zero; soffset (the K position) < one row <= records
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
+
+    // staging: piece q = 8 i + wave of a half covers its local rows 8 q .. 8 q + 7; local row r' of A half h is tile row
+    // (16 MI) (r' / (8 MI)) + 8 MI h + r' % (8 MI), local row r' of B half h is tile column 64 (r' / 32) + 32 h + r' % 32
+    unsigned st_a[2][NA], st_b[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int q = i * 8 + wave;
+            if (A_UNEVEN && i == NA - 1) q = (NA - 1) * 8 + (wave & 3);          // issued by waves 0-3 (h = 0) / 4-7 (h = 1) only
+            const int rl = q * 8 + (lane >> 3);
+            const int r = (C::MI * 16) * (rl / (8 * C::MI)) + 8 * C::MI * h + rl % (8 * C::MI);
+            const int c = (lane & 7) ^ ((rl >> 1) & 7);
+            st_a[h][i] = (unsigned)((long long)r * p.lda * 2) + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int rl = (i * 8 + wave) * 8 + (lane >> 3);
+            const int r = 64 * (rl >> 5) + 32 * h + (rl & 31);
+            const int c = (lane & 7) ^ ((rl >> 1) & 7);
+            st_b[h][i] = (unsigned)((long long)r * p.ldb * 2) + c * 16;
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));    // LDS byte address of the tile buffers
+    // half-tile op `kind` (0: A0, 1: B0, 2: B1, 3: A1) of K-step t into stage buffer t & 1
+    auto stage = [&](auto kind_c, int t) {
+        constexpr int kind = decltype(kind_c)::value;
+        constexpr bool isA = kind == 0 || kind == 3;
+        constexpr int h = (kind == 2 || kind == 3) ? 1 : 0;
+        const unsigned base = lds0 + (t & 1) * STG + (isA ? h * AH : 2 * AH + h * BH);
+        const unsigned so = (unsigned)(t * (BK * 2));
+        if constexpr (isA) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (A_UNEVEN && i == NA - 1) {
+                    if (wr == h) dma16s_at(ra, base + ((NA - 1) * 8 + (wave & 3)) * 1024, st_a[h][i], so);
+                } else {
+                    dma16s_at(ra, base + (i * 8 + wave) * 1024, st_a[h][i], so);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) dma16s_at(rb, base + (i * 8 + wave) * 1024, st_b[h][i], so);
+        }
+    };
+
+    // fragment read offsets within a stage buffer (half 0; half 1 = + AH / + BH as an immediate)
+    const int fr = lane & 15, fg = lane >> 4;
+    const int swz = (fg ^ ((fr >> 1) & 7)) << 4;
+    const int a_rd = (wr * (8 * C::MI) + fr) * 128 + swz;
+    const int b_rd = 2 * AH + (wc * 32 + fr) * 128 + swz;
+
+    f32x4_t acc[C::MI][4];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t a[MH][2], b0[2][2], b1[2][2];
+
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // one phase of K-step kt.  ST: issue this phase's half-tile op; WAIT: vmcnt to wait for before the barrier (-1: none)
+    auto phase = [&](auto P_c, auto ST_c, auto WAIT_c, int kt) {
+        constexpr int P = decltype(P_c)::value;
+        constexpr bool ST = decltype(ST_c)::value;
+        constexpr int WAIT = decltype(WAIT_c)::value;
+        const char* sa = smem + (kt & 1) * STG;
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) b0[nl][ks] = lds_read_b128(sa + ((b_rd ^ (ks << 6)) + nl * 2048));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = lds_read_b128(sa + ((a_rd ^ (ks << 6)) + ml * 2048));
+        } else if constexpr (P == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) b1[nl][ks] = lds_read_b128(sa + ((b_rd ^ (ks << 6)) + BH + nl * 2048));
+        } else if constexpr (P == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = lds_read_b128(sa + ((a_rd ^ (ks << 6)) + AH + ml * 2048));
+        }
+        if constexpr (ST) {
+            // global phase g = 4 kt + P issues op g + 6: B1 / A1 of K-step kt + 1 in phases 0 / 1, A0 / B0 of kt + 2 in 2 / 3
+            if constexpr (P == 0) stage(I2{}, kt + 1);
+            else if constexpr (P == 1) stage(I3{}, kt + 1);
+            else if constexpr (P == 2) stage(I0{}, kt + 2);
+            else stage(I1{}, kt + 2);
+        }
+        if constexpr (WAIT >= 0) wait_vm<WAIT>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0), through the builtin: hipcc's own counter restarts at 0
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int mh = (P >= 2) ? MH : 0;                    // first row tile of the quadrant
+        constexpr int nh = (P == 1 || P == 2) ? 2 : 0;           // first column tile
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ml = 0; ml < MH; ++ml)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl)
+                    acc[mh + ml][nh + nl] = mfma16((P == 1 || P == 2) ? b1[nl][ks] : b0[nl][ks], a[ml][ks], acc[mh + ml][nh + nl]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using T = std::true_type; using F = std::false_type;
+    using WN_ = std::integral_constant<int, -1>;                    // no wait
+    using WF = std::integral_constant<int, W4>;                     // steady state: four ops in flight
+    // tail counts (no further ops are issued after phase 1 of K-step nk - 2)
+    constexpr int nA1_g0 = A_UNEVEN ? NA - 1 : NA, nA1_g1 = NA;     // DMA instructions of an A1 op per wave group
+    using WT2_0 = std::integral_constant<int, NB + nA1_g0>; using WT2_1 = std::integral_constant<int, NB + nA1_g1>;
+    using WT1_0 = std::integral_constant<int, nA1_g0>;      using WT1_1 = std::integral_constant<int, nA1_g1>;
+    using W0 = std::integral_constant<int, 0>;
+
+    // prologue: ops 0 .. 5 (K-step 0 whole, A0 and B0 of K-step 1); A0, B0 of K-step 0 landed before the first barrier
+    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0); stage(I0{}, 1); stage(I1{}, 1);
+    wait_vm<W4>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                      // stagger: waves 4-7 one barrier behind
+
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) {
+        phase(I0{}, T{}, WF{}, kt);
+        phase(I1{}, T{}, WF{}, kt);
+        phase(I2{}, T{}, WN_{}, kt);
+        phase(I3{}, T{}, WF{}, kt);
+    }
+    // K-step nk - 2: ops B1, A1 of the last K-step are the last ones
+    phase(I0{}, T{}, WF{}, kt);
+    phase(I1{}, T{}, WF{}, kt);
+    phase(I2{}, F{}, WN_{}, kt);
+    if (wr == 0) phase(I3{}, F{}, WT2_0{}, kt); else phase(I3{}, F{}, WT2_1{}, kt);
+    ++kt;
+    if (wr == 0) phase(I0{}, F{}, WT1_0{}, kt); else phase(I0{}, F{}, WT1_1{}, kt);
+    phase(I1{}, F{}, W0{}, kt);
+    phase(I2{}, F{}, WN_{}, kt);
+    phase(I3{}, F{}, WN_{}, kt);
+    if (wr == 0) __builtin_amdgcn_s_barrier();                      // re-align the wave groups
+    // the last barrier passed by waves 4-7 closes their last MFMA section: the tile buffers are free for the epilogue patches
+    epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN kernel.  LDS tile image: [64 token rows][TBM (A) / TBN (B) cols] bf16, rows of 256 / 512 / 768 bytes; the 32-byte
 // unit u of row R is stored at unit position u ^ (R & 7) (rows are multiples of 8 units, so the XOR stays inside the
 // row): conflict-free ds_read_b64_tr_b16 (a 32-lane half reads 8 rows x 32 bytes).  Both operands are read with the same
@@ -848,6 +1060,21 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
     return 0;
 }
 
+template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
+int launch_nt8_cfg(GemmNTParams p, hipStream_t s) {
+    static int attr = set_lds(gemm_nt8_kernel<C, EPI, OUT_F32, AUX_F32>, C::LDS);
+    if (attr != 0) return attr;
+    const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
+    p.tiles_n = tiles_n;
+    p.gn = 4;
+#ifdef NRV_DEV_GN
+    p.gn = NRV_DEV_GN;      // tools/build_dev.py only
+#endif
+    hipLaunchKernelGGL((gemm_nt8_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
 // tile selection
 int device_cus() {
     static int n = [] {
@@ -899,6 +1126,19 @@ int launch_nt(const GemmNTParams& p, hipStream_t s) {
     if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
         return launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);    // one launch per step: 256-row tiles only
     if (tc == 1384) return launch_nt_cfg<Cfg384n, EPI, OUT_F32, AUX_F32, false>(p, s);
+#ifndef NRV_DEV_NO_PHASED
+    // phased main loop: whole K-steps only, and at least three of them (its prologue issues 1.5 K-steps, its tail peels two)
+    if ((p.K & (BK - 1)) == 0 && p.K >= 3 * BK) {
+#ifdef NRV_DEV_PHASED_320
+        if (tc == 320) return launch_nt8_cfg<Cfg320, EPI, OUT_F32, AUX_F32>(p, s);
+#else
+        if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
+#endif
+        if (tc == 192) return launch_nt8_cfg<Cfg192, EPI, OUT_F32, AUX_F32>(p, s);
+        if (tc == 128) return launch_nt8_cfg<Cfg128, EPI, OUT_F32, AUX_F32>(p, s);
+        return launch_nt8_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
+    }
+#endif
     if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 192) return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32, false>(p, s);
