@@ -171,6 +171,9 @@ __device__ __forceinline__ void dma16s_at(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 __device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {
     return *reinterpret_cast<const bf16x8_t*>(p);
 }
+__device__ __forceinline__ bf16x8_t lds_read_b128_at(unsigned lds_addr) {      // by LDS byte address
+    return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8_t*>(static_cast<uintptr_t>(lds_addr));
+}
 __device__ __forceinline__ bf16x4_t lds_read_tr16_b64(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) bf16x4_t*)(p));

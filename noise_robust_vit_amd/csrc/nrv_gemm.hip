@@ -620,31 +620,34 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     const int M = p.e.M, N = p.e.N;
     const int nk = p.K / BK;                                        // host: K % 64 == 0, nk >= 3
 
-    // rows >= M - m0 / >= N - n0 lie behind the records and read as zero; soffset (the K position) < one row <= records
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
+    // One descriptor per half: based at the half's first row / column, records = the valid rows behind it, so that rows
+    // >= M - m0 / >= N - n0 read as zero and the per-lane offsets are the same for both halves.  The K position is the scalar
+    // soffset, which the range check subtracts from the records: a half without a valid row (records 0) keeps soffset 0.
+    const int ar1 = M - m0 - 8 * C::MI, br1 = N - n0 - 32;
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(p.A + (long long)(m0 + (ar1 > 0 ? 8 * C::MI : 0)) * p.lda, (unsigned long long)(ar1 > 0 ? ar1 : 0) * p.lda * 2ull);
+    const __amdgpu_buffer_rsrc_t rb0 = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
+    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(p.B + (long long)(n0 + (br1 > 0 ? 32 : 0)) * p.ldb, (unsigned long long)(br1 > 0 ? br1 : 0) * p.ldb * 2ull);
+    const unsigned ka1 = ar1 > 0 ? ~0u : 0u, kb1 = br1 > 0 ? ~0u : 0u;
 
     // staging: piece q = 8 i + wave of a half covers its local rows 8 q .. 8 q + 7; local row r' of A half h is tile row
     // (16 MI) (r' / (8 MI)) + 8 MI h + r' % (8 MI), local row r' of B half h is tile column 64 (r' / 32) + 32 h + r' % 32
-    unsigned st_a[2][NA], st_b[2][NB];
+    unsigned st_a[NA], st_b[NB];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int i = 0; i < NA; ++i) {
+        int q = i * 8 + wave;
+        if (A_UNEVEN && i == NA - 1) q = (NA - 1) * 8 + (wave & 3);          // issued by waves 0-3 (h = 0) / 4-7 (h = 1) only
+        const int rl = q * 8 + (lane >> 3);
+        const int r = (C::MI * 16) * (rl / (8 * C::MI)) + rl % (8 * C::MI);
+        const int c = (lane & 7) ^ ((rl >> 1) & 7);
+        st_a[i] = (unsigned)((long long)r * p.lda * 2) + c * 16;
+    }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int q = i * 8 + wave;
-            if (A_UNEVEN && i == NA - 1) q = (NA - 1) * 8 + (wave & 3);          // issued by waves 0-3 (h = 0) / 4-7 (h = 1) only
-            const int rl = q * 8 + (lane >> 3);
-            const int r = (C::MI * 16) * (rl / (8 * C::MI)) + 8 * C::MI * h + rl % (8 * C::MI);
-            const int c = (lane & 7) ^ ((rl >> 1) & 7);
-            st_a[h][i] = (unsigned)((long long)r * p.lda * 2) + c * 16;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int rl = (i * 8 + wave) * 8 + (lane >> 3);
-            const int r = 64 * (rl >> 5) + 32 * h + (rl & 31);
-            const int c = (lane & 7) ^ ((rl >> 1) & 7);
-            st_b[h][i] = (unsigned)((long long)r * p.ldb * 2) + c * 16;
-        }
+    for (int i = 0; i < NB; ++i) {
+        const int rl = (i * 8 + wave) * 8 + (lane >> 3);
+        const int r = 64 * (rl >> 5) + (rl & 31);
+        const int c = (lane & 7) ^ ((rl >> 1) & 7);
+        st_b[i] = (unsigned)((long long)r * p.ldb * 2) + c * 16;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));    // LDS byte address of the tile buffers
     // half-tile op `kind` (0: A0, 1: B0, 2: B1, 3: A1) of K-step t into stage buffer t & 1
@@ -653,27 +656,35 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         constexpr bool isA = kind == 0 || kind == 3;
         constexpr int h = (kind == 2 || kind == 3) ? 1 : 0;
         const unsigned base = lds0 + (t & 1) * STG + (isA ? h * AH : 2 * AH + h * BH);
-        const unsigned so = (unsigned)(t * (BK * 2));
+        unsigned so = (unsigned)(t * (BK * 2));
+        if constexpr (h == 1) so &= isA ? ka1 : kb1;
         if constexpr (isA) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (A_UNEVEN && i == NA - 1) {
-                    if (wr == h) dma16s_at(ra, base + ((NA - 1) * 8 + (wave & 3)) * 1024, st_a[h][i], so);
+                    if (wr == h) dma16s_at(h ? ra1 : ra0, base + ((NA - 1) * 8 + (wave & 3)) * 1024, st_a[i], so);
                 } else {
-                    dma16s_at(ra, base + (i * 8 + wave) * 1024, st_a[h][i], so);
+                    dma16s_at(h ? ra1 : ra0, base + (i * 8 + wave) * 1024, st_a[i], so);
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) dma16s_at(rb, base + (i * 8 + wave) * 1024, st_b[h][i], so);
+            for (int i = 0; i < NB; ++i) dma16s_at(h ? rb1 : rb0, base + (i * 8 + wave) * 1024, st_b[i], so);
         }
     };
 
-    // fragment read offsets within a stage buffer (half 0; half 1 = + AH / + BH as an immediate)
+    // fragment read addresses (LDS byte addresses of k-step 0 / 1 in the CURRENT stage buffer, half 0; half 1 = + AH / + BH
+    // as an immediate); they move to the other stage buffer in place after every K-step (no per-K-step copies)
     const int fr = lane & 15, fg = lane >> 4;
     const int swz = (fg ^ ((fr >> 1) & 7)) << 4;
-    const int a_rd = (wr * (8 * C::MI) + fr) * 128 + swz;
-    const int b_rd = 2 * AH + (wc * 32 + fr) * 128 + swz;
+    unsigned ard[2], brd[2];
+    ard[0] = lds0 + (wr * (8 * C::MI) + fr) * 128 + swz;      ard[1] = ard[0] ^ 64u;
+    brd[0] = lds0 + 2 * AH + (wc * 32 + fr) * 128 + swz;      brd[1] = brd[0] ^ 64u;
+    int dstg = STG;
+    auto next_stage = [&]() {
+        ard[0] += dstg; ard[1] += dstg; brd[0] += dstg; brd[1] += dstg;
+        dstg = -dstg;
+    };
 
     f32x4_t acc[C::MI][4];
 #pragma unroll
@@ -690,26 +701,25 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         constexpr int P = decltype(P_c)::value;
         constexpr bool ST = decltype(ST_c)::value;
         constexpr int WAIT = decltype(WAIT_c)::value;
-        const char* sa = smem + (kt & 1) * STG;
         if constexpr (P == 0) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int nl = 0; nl < 2; ++nl) b0[nl][ks] = lds_read_b128(sa + ((b_rd ^ (ks << 6)) + nl * 2048));
+                for (int nl = 0; nl < 2; ++nl) b0[nl][ks] = lds_read_b128_at(brd[ks] + nl * 2048);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = lds_read_b128(sa + ((a_rd ^ (ks << 6)) + ml * 2048));
+                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = lds_read_b128_at(ard[ks] + ml * 2048);
         } else if constexpr (P == 1) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int nl = 0; nl < 2; ++nl) b1[nl][ks] = lds_read_b128(sa + ((b_rd ^ (ks << 6)) + BH + nl * 2048));
+                for (int nl = 0; nl < 2; ++nl) b1[nl][ks] = lds_read_b128_at(brd[ks] + BH + nl * 2048);
         } else if constexpr (P == 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = lds_read_b128(sa + ((a_rd ^ (ks << 6)) + AH + ml * 2048));
+                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = lds_read_b128_at(ard[ks] + AH + ml * 2048);
         }
         if constexpr (ST) {
             // global phase g = 4 kt + P issues op g + 6: B1 / A1 of K-step kt + 1 in phases 0 / 1, A0 / B0 of kt + 2 in 2 / 3
@@ -740,10 +750,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     using T = std::true_type; using F = std::false_type;
     using WN_ = std::integral_constant<int, -1>;                    // no wait
     using WF = std::integral_constant<int, W4>;                     // steady state: four ops in flight
-    // tail counts (no further ops are issued after phase 1 of K-step nk - 2)
-    constexpr int nA1_g0 = A_UNEVEN ? NA - 1 : NA, nA1_g1 = NA;     // DMA instructions of an A1 op per wave group
-    using WT2_0 = std::integral_constant<int, NB + nA1_g0>; using WT2_1 = std::integral_constant<int, NB + nA1_g1>;
-    using WT1_0 = std::integral_constant<int, nA1_g0>;      using WT1_1 = std::integral_constant<int, nA1_g1>;
+    // tail counts (no further ops are issued after phase 1 of K-step nk - 2).  With an uneven A split the two wave groups
+    // have NA - 1 / NA instructions in their last A1 op: the smaller count is safe for both (and keeps the tail branch-free)
+    constexpr int nA1 = A_UNEVEN ? NA - 1 : NA;
+    using WT2 = std::integral_constant<int, NB + nA1>;
+    using WT1 = std::integral_constant<int, nA1>;
     using W0 = std::integral_constant<int, 0>;
 
     // prologue: ops 0 .. 5 (K-step 0 whole, A0 and B0 of K-step 1); A0, B0 of K-step 0 landed before the first barrier
@@ -758,14 +769,16 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         phase(I1{}, T{}, WF{}, kt);
         phase(I2{}, T{}, WN_{}, kt);
         phase(I3{}, T{}, WF{}, kt);
+        next_stage();
     }
     // K-step nk - 2: ops B1, A1 of the last K-step are the last ones
     phase(I0{}, T{}, WF{}, kt);
     phase(I1{}, T{}, WF{}, kt);
     phase(I2{}, F{}, WN_{}, kt);
-    if (wr == 0) phase(I3{}, F{}, WT2_0{}, kt); else phase(I3{}, F{}, WT2_1{}, kt);
+    phase(I3{}, F{}, WT2{}, kt);
+    next_stage();
     ++kt;
-    if (wr == 0) phase(I0{}, F{}, WT1_0{}, kt); else phase(I0{}, F{}, WT1_1{}, kt);
+    phase(I0{}, F{}, WT1{}, kt);
     phase(I1{}, F{}, W0{}, kt);
     phase(I2{}, F{}, WN_{}, kt);
     phase(I3{}, F{}, WN_{}, kt);
@@ -1129,11 +1142,7 @@ int launch_nt(const GemmNTParams& p, hipStream_t s) {
 #ifndef NRV_DEV_NO_PHASED
     // phased main loop: whole K-steps only, and at least three of them (its prologue issues 1.5 K-steps, its tail peels two)
     if ((p.K & (BK - 1)) == 0 && p.K >= 3 * BK) {
-#ifdef NRV_DEV_PHASED_320
         if (tc == 320) return launch_nt8_cfg<Cfg320, EPI, OUT_F32, AUX_F32>(p, s);
-#else
-        if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
-#endif
         if (tc == 192) return launch_nt8_cfg<Cfg192, EPI, OUT_F32, AUX_F32>(p, s);
         if (tc == 128) return launch_nt8_cfg<Cfg128, EPI, OUT_F32, AUX_F32>(p, s);
         return launch_nt8_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);

@@ -5,5 +5,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT
 cd $ROOT
+LIBS=${1:-base,product}
 timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm_nt" > $OUT/a_tests.log 2>&1; echo "pytest exit $?"; tail -3 $OUT/a_tests.log
-only=nt timeout -k 10 500 python tools/gemm_bench.py base,product 5 > $OUT/a_bench.log 2>&1; echo "bench exit $?"; cat $OUT/a_bench.log
+only=nt timeout -k 10 500 python tools/gemm_bench.py $LIBS 5 > $OUT/a_bench.log 2>&1; echo "bench exit $?"; cat $OUT/a_bench.log
