@@ -178,6 +178,10 @@ __device__ __forceinline__ bf16x4_t lds_read_tr16_b64(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) bf16x4_t*)(p));
 }
+__device__ __forceinline__ bf16x4_t lds_read_tr16_b64_at(unsigned lds_addr) {  // by LDS byte address
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) bf16x4_t*>(static_cast<uintptr_t>(lds_addr)));
+}
 __device__ __forceinline__ bf16x8_t cat4(bf16x4_t a, bf16x4_t b) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }

@@ -88,7 +88,7 @@ struct GemmTNParams {
     long long lda, ldb;
     int T;
     int tiles_n, tiles_mn;
-    int splits, kt_per_split;     // K-tiles (of 64 token rows) per split
+    int splits, kt_q, kt_r;       // K-tiles (of 64 token rows) per split: kt_q, the first kt_r splits one more
     int a_group, a_group_stride, a_row_offset;
     long long slab_stride;        // elements between split slabs (0 when splits == 1)
     float* bias_ws;               // optional [splits][M] column sums of A (bias gradient), nullptr = off
@@ -828,8 +828,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     const int m0 = tm * C::TBM, n0 = tn * C::TBN;
     const int M = p.e.M, N = p.e.N;
 
-    const int t_begin = split * p.kt_per_split * BK;
-    int t_end = t_begin + p.kt_per_split * BK;
+    const int t_begin = (split * p.kt_q + (split < p.kt_r ? split : p.kt_r)) * BK;
+    int t_end = t_begin + (p.kt_q + (split < p.kt_r ? 1 : 0)) * BK;
     if (t_end > p.T) t_end = p.T;
     const int nk = t_end > t_begin ? (t_end - t_begin + BK - 1) / BK : 0;
 
@@ -983,6 +983,238 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
                     if (m < M) p.bias_ws[(long long)split * M + m] = accb[b][j][0];
                 }
             }
+        }
+    }
+    EpiParams e = p.e;
+    e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
+    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, smem, e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel, phased K loop: the schedule of gemm_nt8_kernel (four phases per K-step of 64 token rows, waves 4-7 one barrier
+// behind, half-tile LDS-DMA ops issued six phases ahead of their first read, ONE counted vmcnt value) on the TN operand
+// images.  A half image = [64 token rows][the 8 MI columns of half h of both wave rows] (256-byte rows, 32-byte units
+// swizzled by the row), B half image = [64 token rows][the 32 columns of half h of the four wave columns]; both are read
+// with ds_read_b64_tr_b16.  Host: no row remap, every split has at least three K-steps.
+// ---------------------------------------------------------------------------------------------
+template <typename C>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNParams p) {
+    static_assert(C::WM == 2 && C::WN == 4 && C::MI % 2 == 0, "2 x 4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MH = C::MI / 2;
+    constexpr int RAH = C::TBM, RBH = C::TBN;                 // bytes per token row of a half image (TBM / 2 columns x 2 bytes)
+    constexpr int AH = BK * RAH, BH = BK * RBH, STG = 2 * AH + 2 * BH;
+    constexpr int NA = AH / 8192, NB = BH / 8192;             // DMA instructions per wave and half-tile op
+    static_assert(AH % 8192 == 0 && BH % 8192 == 0 && RAH % 256 == 0 && RBH % 256 == 0, "whole pieces, rows of 8 units");
+    constexpr int W4 = 2 * NA + 2 * NB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / p.tiles_mn;
+    const int tile = id - split * p.tiles_mn;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * C::TBM, n0 = tn * C::TBN;
+    const int M = p.e.M, N = p.e.N;
+    const int nk = p.kt_q + (split < p.kt_r ? 1 : 0);        // >= 3 (host)
+    const int t_begin = (split * p.kt_q + (split < p.kt_r ? split : p.kt_r)) * BK;
+    int t_end = t_begin + nk * BK;
+    if (t_end > p.T) t_end = p.T;
+    const int trem = t_end - t_begin;                         // > 64 (nk - 1) >= 128
+
+    const int acols = M - m0 < C::TBM ? M - m0 : C::TBM, bcols = N - n0 < C::TBN ? N - n0 : C::TBN;
+    // records end with the last valid column of the split's last token row: rows >= t_end read as zero, the K position is
+    // the scalar soffset (< the records for every K-step of the split)
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)t_begin * p.lda + m0, ((unsigned long long)(trem - 1) * p.lda + acols) * 2ull);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)t_begin * p.ldb + n0, ((unsigned long long)(trem - 1) * p.ldb + bcols) * 2ull);
+
+    // staging: piece 8 i + wave of a half image is lane-linear: lane -> (token row R, 16-byte position); the unit swizzle is
+    // applied to the SOURCE column; column c' of A half h is tile column (16 MI)(c' / (8 MI)) + 8 MI h + c' % (8 MI), of B
+    // half h tile column 64 (c' / 32) + 32 h + c' % 32
+    unsigned va[2][NA], vb[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int L = (i * 8 + wave) * 1024 + lane * 16;
+            const int R = L / RAH, pos = (L - R * RAH) >> 4;
+            const int ch = ((((pos >> 1) ^ (R & 7)) << 1) + (pos & 1)) * 8;
+            const int col = (16 * C::MI) * (ch / (8 * C::MI)) + 8 * C::MI * h + ch % (8 * C::MI);
+            va[h][i] = col < acols ? (unsigned)(((long long)R * p.lda + col) * 2) : NRV_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int L = (i * 8 + wave) * 1024 + lane * 16;
+            const int R = L / RBH, pos = (L - R * RBH) >> 4;
+            const int ch = ((((pos >> 1) ^ (R & 7)) << 1) + (pos & 1)) * 8;
+            const int col = 64 * (ch >> 5) + 32 * h + (ch & 31);
+            vb[h][i] = col < bcols ? (unsigned)(((long long)R * p.ldb + col) * 2) : NRV_OOB;
+        }
+    }
+    const unsigned a_step = (unsigned)(BK * p.lda * 2), b_step = (unsigned)(BK * p.ldb * 2);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));
+    auto stage = [&](auto kind_c, int t) {                    // op kind 0: A0, 1: B0, 2: B1, 3: A1 of K-step t
+        constexpr int kind = decltype(kind_c)::value;
+        constexpr bool isA = kind == 0 || kind == 3;
+        constexpr int h = (kind == 2 || kind == 3) ? 1 : 0;
+        const unsigned base = lds0 + (t & 1) * STG + (isA ? h * AH : 2 * AH + h * BH);
+        if constexpr (isA) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) dma16s_at(ra, base + (i * 8 + wave) * 1024, va[h][i], (unsigned)t * a_step);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) dma16s_at(rb, base + (i * 8 + wave) * 1024, vb[h][i], (unsigned)t * b_step);
+        }
+    };
+
+    // transposed fragment reads: lane (g = l >> 4, q = (l & 15) >> 2, pp = l & 3) supplies row 4 g + q (+ 16 for the second
+    // read, + 32 per k-step), unit (16-column block) u of the wave ^ (row & 7), 8 pp bytes into it
+    const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+    const int Rl = 4 * fg + fq;
+    const int x = Rl & 7;
+    unsigned a_off[MH], b_off[2];
+#pragma unroll
+    for (int ml = 0; ml < MH; ++ml) a_off[ml] = lds0 + Rl * RAH + (((wr * MH + ml) ^ x) << 5) + fp * 8;
+#pragma unroll
+    for (int nl = 0; nl < 2; ++nl) b_off[nl] = lds0 + 2 * AH + Rl * RBH + (((wc * 2 + nl) ^ x) << 5) + fp * 8;
+    int dstg = STG;
+    auto next_stage = [&]() {
+#pragma unroll
+        for (int ml = 0; ml < MH; ++ml) a_off[ml] += dstg;
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) b_off[nl] += dstg;
+        dstg = -dstg;
+    };
+    auto ld_a = [&](int h, int ml, int ks) {
+        const unsigned q = a_off[ml] + h * AH + ks * (32 * RAH);
+        return cat4(lds_read_tr16_b64_at(q), lds_read_tr16_b64_at(q + 16 * RAH));
+    };
+    auto ld_b = [&](int h, int nl, int ks) {
+        const unsigned q = b_off[nl] + h * BH + ks * (32 * RBH);
+        return cat4(lds_read_tr16_b64_at(q), lds_read_tr16_b64_at(q + 16 * RBH));
+    };
+
+    f32x4_t acc[C::MI][4];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t a[MH][2], b0[2][2], b1[2][2];
+
+    // fused bias gradient db[m] = sum_t A[t, m] = (ones . A) on the MFMA, first column tile only; wave column wc takes the row
+    // blocks 2 wc, 2 wc + 1 of its wave row: half wc >> 1, fragments (wc & 1) * MH / 2 + {0, 1}
+    static_assert(MH == 4, "bias-gradient block assignment");
+    const bool do_bias = p.bias_ws != nullptr && tn == 0;
+    const u32x4_t ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
+    f32x4_t accb[2];
+    accb[0] = accb[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    auto phase = [&](auto P_c, auto ST_c, auto WAIT_c, int kt) {
+        constexpr int P = decltype(P_c)::value;
+        constexpr bool ST = decltype(ST_c)::value;
+        constexpr int WAIT = decltype(WAIT_c)::value;
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) b0[nl][ks] = ld_b(0, nl, ks);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = ld_a(0, ml, ks);
+        } else if constexpr (P == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) b1[nl][ks] = ld_b(1, nl, ks);
+        } else if constexpr (P == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = ld_a(1, ml, ks);
+        }
+        if constexpr (ST) {
+            if constexpr (P == 0) stage(I2{}, kt + 1);
+            else if constexpr (P == 1) stage(I3{}, kt + 1);
+            else if constexpr (P == 2) stage(I0{}, kt + 2);
+            else stage(I1{}, kt + 2);
+        }
+        if constexpr (WAIT >= 0) wait_vm<WAIT>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int mh = (P >= 2) ? MH : 0;
+        constexpr int nh = (P == 1 || P == 2) ? 2 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ml = 0; ml < MH; ++ml)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl)
+                    acc[mh + ml][nh + nl] = mfma16((P == 1 || P == 2) ? b1[nl][ks] : b0[nl][ks], a[ml][ks], acc[mh + ml][nh + nl]);
+        if constexpr (P == 0 || P == 2) {
+            if (do_bias && (wc >> 1) == P / 2) {              // uniform
+                if (wc & 1) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, a[2 + j][ks], accb[j]);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, a[j][ks], accb[j]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using T = std::true_type; using F = std::false_type;
+    using WN_ = std::integral_constant<int, -1>;
+    using WF = std::integral_constant<int, W4>;
+    using WT2 = std::integral_constant<int, NB + NA>;
+    using WT1 = std::integral_constant<int, NA>;
+    using W0 = std::integral_constant<int, 0>;
+
+    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0); stage(I0{}, 1); stage(I1{}, 1);
+    wait_vm<W4>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) {
+        phase(I0{}, T{}, WF{}, kt);
+        phase(I1{}, T{}, WF{}, kt);
+        phase(I2{}, T{}, WN_{}, kt);
+        phase(I3{}, T{}, WF{}, kt);
+        next_stage();
+    }
+    phase(I0{}, T{}, WF{}, kt);
+    phase(I1{}, T{}, WF{}, kt);
+    phase(I2{}, F{}, WN_{}, kt);
+    phase(I3{}, F{}, WT2{}, kt);
+    next_stage();
+    ++kt;
+    phase(I0{}, F{}, WT1{}, kt);
+    phase(I1{}, F{}, W0{}, kt);
+    phase(I2{}, F{}, WN_{}, kt);
+    phase(I3{}, F{}, WN_{}, kt);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    if (do_bias && lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wr * (C::MI * 16) + (2 * wc + j) * 16 + lane;
+            if (m < M) p.bias_ws[(long long)split * M + m] = accb[j][0];
         }
     }
     EpiParams e = p.e;
@@ -1271,7 +1503,8 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     const TnPlan pl = tn_plan(M, N, T);
     const int splits = pl.splits;
     const int64_t kt_total = nrv_cdiv(T, BK);
-    const int kt_per_split = (int)nrv_cdiv(kt_total, splits);
+    const int kt_q = (int)(kt_total / splits), kt_r = (int)(kt_total % splits);
+    const int kt_per_split = kt_q + (kt_r ? 1 : 0);
     // per-workgroup operand windows must stay below 2 GiB of byte offset
     const int64_t a_rows = a_group > 0 ? (int64_t)kt_per_split * BK * a_group_stride / a_group + a_group_stride : (int64_t)kt_per_split * BK;
     if (a_rows * lda * 2 >= 0x7fffffffll || (int64_t)kt_per_split * BK * ldb * 2 >= 0x7fffffffll) return NRV_ERR_SHAPE;
@@ -1287,7 +1520,7 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.B = static_cast<const bf16_t*>(B);
     p.lda = lda; p.ldb = ldb; p.T = (int)T;
     p.tiles_n = pl.tiles_n; p.tiles_mn = pl.tiles_m * pl.tiles_n;
-    p.splits = splits; p.kt_per_split = kt_per_split;
+    p.splits = splits; p.kt_q = kt_q; p.kt_r = kt_r;
     p.a_group = (int)a_group; p.a_group_stride = (int)a_group_stride; p.a_row_offset = (int)a_row_offset;
     p.e.bias = nullptr; p.e.aux = nullptr; p.e.aux_out = nullptr;
     p.e.ld_aux = 0; p.e.ld_aux_out = 0;
@@ -1303,6 +1536,13 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
         static int attr = set_lds(gemm_tn_kernel<TnCfg384>, TnCfg384::LDS);
         if (attr != 0) return attr;
         hipLaunchKernelGGL(gemm_tn_kernel<TnCfg384>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg384::LDS, s, p);
+    } else
+#endif
+#ifndef NRV_DEV_NO_PHASED
+    if (a_group == 0 && kt_q >= 3) {          // phased K loop: no row remap, at least three K-steps in every split
+        static int attr = set_lds(gemm_tn8_kernel<TnCfg256>, TnCfg256::LDS);
+        if (attr != 0) return attr;
+        hipLaunchKernelGGL(gemm_tn8_kernel<TnCfg256>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg256::LDS, s, p);
     } else
 #endif
     {
