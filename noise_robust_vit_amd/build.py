@@ -50,7 +50,7 @@ def _compile(src: str, force: bool, objdir: str = OBJ, extra: tuple = (), csrc: 
     path = os.path.join(csrc, src)
     if force or _stale(obj, [path] + _deps(csrc)):
         flags = [f if f != "-I" + CSRC else "-I" + csrc for f in FLAGS]
-        cmd = [_hipcc()] + flags + list(extra) + ["-c", path, "-o", obj]
+        cmd = [_hipcc()] + list(extra) + flags + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

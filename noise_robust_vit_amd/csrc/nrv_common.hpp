@@ -142,11 +142,6 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_bas
 // offset constant, so a DMA costs no vector-ALU instruction (the range check subtracts soffset from the record count)
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset, unsigned soffset) {
     const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_base));
-#ifdef NRV_DEV_OLD_M0
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voffset), "s"(rsrc), "s"(lds_addr), "s"(soffset) : "memory");
-#else
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
@@ -154,7 +149,6 @@ __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, void* lds_ba
         :
         : "v"(voffset), "s"(rsrc), "s"(lds_addr), "s"(soffset)
         : "memory", "m0");
-#endif
 }
 
 // the same, LDS destination given as a (wave-uniform) LDS byte address: no generic-pointer cast per instruction

@@ -21,15 +21,14 @@
 
 #include "nrv_common.hpp"
 #include <type_traits>
-
-#ifndef NRV_DMA_GROUPS
-#define NRV_DMA_GROUPS 4
-#endif
+#define NRV_DEV_TU gemm
+#include <nrv_dev.hpp>       // instrumentation hooks: empty in the product (csrc/nrv_dev.hpp)
 
 namespace {
 
 constexpr int BK = 64;                      // K-tile depth of both kernels
 constexpr int GEMM_THREADS = 512;
+constexpr int DMA_GROUPS = 4;               // 2-stage K loops: MFMA groups of a K-step that carry the next K-step's DMA issue (swept 2 .. 8)
 
 // NT tile configurations: WM x WN waves, each wave MI x NI MFMA tiles of 16x16 (NI is 4 everywhere: the
 // epilogue transposes 16 x 64 slabs).  One workgroup per CU.
@@ -76,9 +75,6 @@ struct GemmNTParams {
     int K;
     int tiles_n;
     int gn;                       // column-group width of the tile order (0 = plain row-major sweep)
-#ifdef NRV_DEV_STAMPS
-    unsigned long long* stamps;   // tools/ build only: 4 x s_memrealtime + hw id per workgroup
-#endif
     EpiParams e;
 };
 
@@ -422,13 +418,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
         tm = id / p.tiles_n;
         tn = id - tm * p.tiles_n;
     }
-#ifdef NRV_DEV_SAME_TILE
-    // experiment (tools/build_dev.py only; results are garbage): every workgroup loads and stores tile (0, 0), so that all
-    // operand traffic hits the XCD's L2: the K loop at a 100 % L2 hit rate
-    const int m0 = 0 * tm, n0 = 0 * tn;
-#else
     const int m0 = tm * C::TBM, n0 = tn * C::TBN;
-#endif
     const int M = p.e.M, N = p.e.N, K = p.K;
 
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
@@ -469,7 +459,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
     };
     constexpr int ND = C::CA + C::CB;            // DMA instructions per thread per K-tile
     constexpr int NG = C::MI;                    // MFMA groups per K-tile: 2 k-steps x MI/2 row pairs
-    constexpr int NGD = NRV_DMA_GROUPS < NG ? NRV_DMA_GROUPS : NG;   // groups that carry the next tile's DMA issue
+    constexpr int NGD = DMA_GROUPS < NG ? DMA_GROUPS : NG;   // groups that carry the next tile's DMA issue
 
     // fragment read offsets
     const int fr = lane & 15, fg = lane >> 4;
@@ -483,28 +473,19 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-#ifdef NRV_DEV_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, wait_vm = 0, wait_bar = 0, loop_c0 = 0;
-    if (p.stamps) t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    NRV_STAMP_VARS(4);
+    NRV_WACC_VARS;
+    NRV_STAMP(0);
 #pragma unroll
     for (int d = 0; d < ND; ++d) dma_one(0, 0, d);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-#ifdef NRV_DEV_STAMPS
-        const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-#endif
+        NRV_WACC(2);                                  // section 2: MFMA groups + fragment reads + DMA issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef NRV_DEV_STAMPS
-        const unsigned long long w1 = __builtin_amdgcn_s_memtime();
-#endif
+        NRV_WACC(0);                                  // section 0: parked on vmcnt(0)
         __syncthreads();
-#ifdef NRV_DEV_STAMPS
-        const unsigned long long w2 = __builtin_amdgcn_s_memtime();
-        if (kt > 0) { wait_vm += w1 - w0; wait_bar += w2 - w1; }
-        if (kt == 1) loop_c0 = w0;
-        if (p.stamps && kt == 0) t1 = __builtin_amdgcn_s_memrealtime();
-#endif
+        NRV_WACC(1);                                  // section 1: parked on the barrier
+        if (kt == 0) { NRV_STAMP(1); NRV_WACC_MARK(); }
         const bool more = kt + 1 < nk;
         const char* sa = smem + cur * C::STAGE;
         // The next tile's DMA instructions are spread over the MFMA groups of this tile (each costs the issuing
@@ -540,27 +521,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
         }
     }
     __syncthreads();     // every wave is done with the tile buffers: reuse them as epilogue patches
-#ifdef NRV_DEV_STAMPS
-    if (p.stamps) t2 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long loop_c1 = __builtin_amdgcn_s_memtime();
-#endif
+    NRV_STAMP(2);
     if (REMAP) epilogue_remap<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
     else epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
-#ifdef NRV_DEV_STAMPS
-    if (p.stamps) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long* o = p.stamps + (unsigned long long)blockIdx.x * 5;
-            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_memrealtime();
-            o[4] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4 /* HW_REG_HW_ID */) | ((unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20 /* XCC_ID */) << 32);
-        }
-        if (lane == 0) {        // per wave, K-tiles 1 .. nk-1: shader cycles parked on vmcnt(0), on the barrier, and in total
-            unsigned long long* w = p.stamps + (1u << 19) + ((unsigned long long)blockIdx.x * C::NWAVES + wave) * 3;
-            w[0] = wait_vm; w[1] = wait_bar; w[2] = loop_c1 - loop_c0;
-        }
-    }
-#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no-ops in the product: the hooks below are empty
+    NRV_STAMP(3);
+    NRV_STAMP_FLUSH_WG(4, tid);
+    NRV_WACC_FLUSH(C::NWAVES, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -602,6 +569,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    NRV_STAMP_VARS(4);
+    NRV_WACC_VARS;
+    NRV_STAMP(0);
 
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -728,10 +698,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
             else if constexpr (P == 2) stage(I0{}, kt + 2);
             else stage(I1{}, kt + 2);
         }
+        NRV_WACC(4 * P + 0);                                      // per phase P: section 0: fragment-read and DMA issue
         if constexpr (WAIT >= 0) wait_vm<WAIT>();
+        NRV_WACC(4 * P + 1);                                      // section 1: counted vmcnt wait
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0), through the builtin: hipcc's own counter restarts at 0
+        NRV_WACC(4 * P + 2);                                      // section 2: barrier + fragment-read latency
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         constexpr int mh = (P >= 2) ? MH : 0;                    // first row tile of the quadrant
@@ -746,6 +719,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        NRV_WACC(4 * P + 3);                                      // section 3: MFMA section + closing barrier
     };
     using T = std::true_type; using F = std::false_type;
     using WN_ = std::integral_constant<int, -1>;                    // no wait
@@ -762,6 +736,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     wait_vm<W4>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                      // stagger: waves 4-7 one barrier behind
+    NRV_STAMP(1);
+    NRV_WACC_MARK();
 
     int kt = 0;
     for (; kt < nk - 2; ++kt) {
@@ -783,8 +759,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     phase(I2{}, F{}, WN_{}, kt);
     phase(I3{}, F{}, WN_{}, kt);
     if (wr == 0) __builtin_amdgcn_s_barrier();                      // re-align the wave groups
+    NRV_STAMP(2);
     // the last barrier passed by waves 4-7 closes their last MFMA section: the tile buffers are free for the epilogue patches
     epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // stamp hooks below are empty in the product
+    NRV_STAMP(3);
+    NRV_STAMP_FLUSH_WG(4, tid);
+    NRV_WACC_FLUSH(C::NWAVES, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -794,9 +775,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
 // transposed pattern, so the k-order permutation inside a 32-deep MFMA step is the same for A and B.
 //
 // Tile configurations (8 waves as WM x WN, wave block (16 MI) x 64, 64 KiB of operands per K-tile in both):
-//   TnCfg256: 256 x 256 -- the product's only TN tile
-//   TnCfg384: 384 x 128 -- developer builds only (-DNRV_DEV_TN_TILE=384): removes the 25-44 % padding of a 256 x 256 grid on
-//             the ViT-S widths (384, 1152, 1536) and wins in isolated launches, loses inside the step (tn_plan)
+//   TnCfg256: 256 x 256 -- the only TN tile (a 384 x 128 variant removed the 25-44 % padding of a 256 x 256 grid on the ViT-S
+//             widths and won in isolated launches, but lost inside the step: profiles/r02_step_ab_in_process.txt)
 // ---------------------------------------------------------------------------------------------
 template <int WM_, int WN_, int MI_>
 struct TnCfg {
@@ -812,7 +792,6 @@ struct TnCfg {
     static_assert(MI % 2 == 0, "row blocks are processed in pairs");
 };
 using TnCfg256 = TnCfg<2, 4, 8>;
-using TnCfg384 = TnCfg<4, 2, 6>;
 
 template <typename C>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParams p) {
@@ -888,7 +867,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     };
     constexpr int ND = C::CA + C::CB;
     constexpr int NG = C::MI, GH = C::MI / 2;            // MFMA groups per K-tile: 2 k-steps x MI/2 row-block pairs
-    constexpr int NGD = NRV_DMA_GROUPS < NG ? NRV_DMA_GROUPS : NG;      // groups that carry the next tile's DMA issue
+    constexpr int NGD = DMA_GROUPS < NG ? DMA_GROUPS : NG;      // groups that carry the next tile's DMA issue
 
     // transposed fragment read offsets: lane (g = l>>4, q = (l&15)>>2, pp = l&3) supplies row 4g+q (+16 r + 32 ks);
     // one offset register per 16-column block of the wave (its unit index is not a multiple of 8 in every configuration,
@@ -1269,19 +1248,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-#ifdef NRV_DEV_STAMPS
-// per-workgroup phase stamps: compiled only into the developer library (tools/build_dev.py), never into libnrv_hip.so
-constexpr size_t STAMP_BYTES = 8u << 20;
-unsigned long long* debug_stamp_buffer() {
-    static unsigned long long* buf = [] {
-        void* p = nullptr;
-        if (hipMalloc(&p, STAMP_BYTES) != hipSuccess) p = nullptr;
-        return static_cast<unsigned long long*>(p);
-    }();
-    return buf;
-}
-#endif
-
 template <typename KernelT>
 int set_lds(KernelT k, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1294,12 +1260,6 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
     const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
     p.tiles_n = tiles_n;
     p.gn = 4;               // column groups of 4 tiles per XCD (swept 2, 3, 4, 6, 12, off in round 1: 8192^3 1111 -> 1336 TFLOP/s)
-#ifdef NRV_DEV_GN
-    p.gn = NRV_DEV_GN;      // tools/build_dev.py only
-#endif
-#ifdef NRV_DEV_STAMPS
-    p.stamps = debug_stamp_buffer();
-#endif
     hipLaunchKernelGGL((gemm_nt_kernel<C, EPI, OUT_F32, AUX_F32, REMAP>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
@@ -1312,9 +1272,6 @@ int launch_nt8_cfg(GemmNTParams p, hipStream_t s) {
     const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
     p.tiles_n = tiles_n;
     p.gn = 4;
-#ifdef NRV_DEV_GN
-    p.gn = NRV_DEV_GN;      // tools/build_dev.py only
-#endif
     hipLaunchKernelGGL((gemm_nt8_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
@@ -1333,9 +1290,6 @@ int device_cus() {
 
 int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
     (void)K;
-#ifdef NRV_DEV_TILE
-    return NRV_DEV_TILE;         // tools/build_dev.py only: one fixed tile height for A/B runs
-#endif
     // One workgroup per CU: the kernel takes ceil(tiles / CUs) rounds of one tile time each, and a tile's time grows with
     // its height (MFMA work ~ rows; operand traffic ~ rows + 256).  Pick the height with the smallest rounds x cost;
     // e.g. [50432 x 768]: 591 tiles of 256 rows = 3 rounds, 474 tiles of 320 rows = 2 rounds (0.140 -> 0.121 ms measured);
@@ -1354,11 +1308,7 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
     // Cost 300 per tile from the ViT-S sweep (profiles/r02_nt_tile_sweep_128_column_tiles.txt: 52.5 vs 58.9 us on
     // [50432 x 384 x 1152], 67.0 vs 75.8 on [50432 x 384 x 1536]; both grids take 2 rounds)
     const int64_t tn128 = nrv_cdiv(N, 128);
-#ifdef NRV_DEV_NO_NARROW
-    if (false) {
-#else
     if (tn128 * 128 < tn * 256) {
-#endif
         const double c = (double)nrv_cdiv(nrv_cdiv(M, 384) * tn128, cus) * 300.0;
         if (c < best_cost * 0.999) { best = 1384; best_cost = c; }
     }
@@ -1367,11 +1317,10 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
-    const int tc = nt_tile_choice(p.e.M, p.e.N, p.K);
+    const int tc = NRV_TUNE_NT_TILE(nt_tile_choice(p.e.M, p.e.N, p.K));      // identity in the product (csrc/nrv_dev.hpp)
     if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
         return launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);    // one launch per step: 256-row tiles only
     if (tc == 1384) return launch_nt_cfg<Cfg384n, EPI, OUT_F32, AUX_F32, false>(p, s);
-#ifndef NRV_DEV_NO_PHASED
     // phased main loop: whole K-steps only, and at least three of them (its prologue issues 1.5 K-steps, its tail peels two)
     if ((p.K & (BK - 1)) == 0 && p.K >= 3 * BK) {
         if (tc == 320) return launch_nt8_cfg<Cfg320, EPI, OUT_F32, AUX_F32>(p, s);
@@ -1379,28 +1328,18 @@ int launch_nt(const GemmNTParams& p, hipStream_t s) {
         if (tc == 128) return launch_nt8_cfg<Cfg128, EPI, OUT_F32, AUX_F32>(p, s);
         return launch_nt8_cfg<Cfg256, EPI, OUT_F32, AUX_F32>(p, s);
     }
-#endif
     if (tc == 320) return launch_nt_cfg<Cfg320, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 192) return launch_nt_cfg<Cfg192, EPI, OUT_F32, AUX_F32, false>(p, s);
     if (tc == 128) return launch_nt_cfg<Cfg128, EPI, OUT_F32, AUX_F32, false>(p, s);
     return launch_nt_cfg<Cfg256, EPI, OUT_F32, AUX_F32, false>(p, s);
 }
 
-// TN launch plan: tile configuration (the one that computes the fewest padded MACs, the 384 x 128 tile weighted by its
-// higher cost per MAC) and the number of token splits that fills the CUs
-struct TnPlan { int cfg; int tiles_m, tiles_n, splits; };
+// TN launch plan: 256 x 256 tiles and the number of token splits that fills the CUs
+struct TnPlan { int tiles_m, tiles_n, splits; };
 TnPlan tn_plan(int64_t M, int64_t N, int64_t T) {
     TnPlan pl;
-    // In isolated back-to-back launches the 384 x 128 tile wins wherever it removes padding (ViT-S dWqkv 72 -> 64 us), but
-    // inside the training step, where the operands are not already in the Infinity Cache, it loses (ViT-S TN total 3.93 ->
-    // 4.18 ms per step: more operand panels per workgroup): profiles/r02_step_ab_in_process.txt.  Developer builds only.
-    int want = 256;
-#ifdef NRV_DEV_TN_TILE
-    want = NRV_DEV_TN_TILE;      // tools/build_dev.py only
-#endif
-    pl.cfg = want;
-    pl.tiles_m = (int)nrv_cdiv(M, want == 384 ? 384 : 256);
-    pl.tiles_n = (int)nrv_cdiv(N, want == 384 ? 128 : 256);
+    pl.tiles_m = (int)nrv_cdiv(M, 256);
+    pl.tiles_n = (int)nrv_cdiv(N, 256);
     const int64_t tiles = (int64_t)pl.tiles_m * pl.tiles_n;
     const int64_t kt = nrv_cdiv(T, BK);
     int64_t s = device_cus() / tiles;
@@ -1474,14 +1413,6 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     }
 }
 
-#ifdef NRV_DEV_STAMPS
-extern "C" int nrv_dev_read_stamps(unsigned long long* host_out, size_t count) {
-    unsigned long long* b = debug_stamp_buffer();
-    if (!b || !host_out || count * 8 > STAMP_BYTES) return NRV_ERR_NULL;
-    return (int)hipMemcpy(host_out, b, count * 8, hipMemcpyDeviceToHost);
-}
-#endif
-
 extern "C" size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T) {
     if (M <= 0 || N <= 0 || T <= 0) return 0;
     const int s = tn_plan(M, N, T).splits;
@@ -1531,21 +1462,11 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.bias_ws = dbias ? reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes) : nullptr;
 
     hipStream_t s = static_cast<hipStream_t>(stream);
-#ifdef NRV_DEV_TN_TILE
-    if (pl.cfg == 384) {
-        static int attr = set_lds(gemm_tn_kernel<TnCfg384>, TnCfg384::LDS);
-        if (attr != 0) return attr;
-        hipLaunchKernelGGL(gemm_tn_kernel<TnCfg384>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg384::LDS, s, p);
-    } else
-#endif
-#ifndef NRV_DEV_NO_PHASED
     if (a_group == 0 && kt_q >= 3) {          // phased K loop: no row remap, at least three K-steps in every split
         static int attr = set_lds(gemm_tn8_kernel<TnCfg256>, TnCfg256::LDS);
         if (attr != 0) return attr;
         hipLaunchKernelGGL(gemm_tn8_kernel<TnCfg256>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg256::LDS, s, p);
-    } else
-#endif
-    {
+    } else {
         static int attr = set_lds(gemm_tn_kernel<TnCfg256>, TnCfg256::LDS);
         if (attr != 0) return attr;
         hipLaunchKernelGGL(gemm_tn_kernel<TnCfg256>, dim3(p.tiles_mn * splits), dim3(GEMM_THREADS), TnCfg256::LDS, s, p);

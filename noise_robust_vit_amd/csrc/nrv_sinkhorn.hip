@@ -20,6 +20,8 @@
 // transposed through an LDS chunk inside the same kernel (nothing [N,N]-sized ever reaches HBM; the reference materialises
 // ~10 fp32 copies).
 #include "nrv_attn_common.hpp"
+#define NRV_DEV_TU sinkhorn
+#include <nrv_dev.hpp>       // instrumentation hooks: empty in the product (csrc/nrv_dev.hpp)
 
 namespace {
 
@@ -27,9 +29,7 @@ using namespace nrv_attn;
 
 constexpr int SK_THREADS = 1024;      // 16 waves: one 16-query tile each (N <= 256)
 constexpr int SK_WAVES = 16;
-#ifndef NRV_SK_TPW
-#define NRV_SK_TPW 2
-#endif
+constexpr int SK_TPW = 2;             // query tiles per wave of the backward kernel
 
 struct SinkParams {
     const bf16_t* qkv;     // [B, N, 3*H*64]
@@ -38,9 +38,6 @@ struct SinkParams {
     bf16_t* dqkv;          // [B, N, 3*H*64]
     float* lse;            // [B, H, N]
     float* scal;           // [B, H, 7, N]   a1 b1 a2 b2 a3 b3 a4
-#ifdef NRV_SK_STAMPS
-    unsigned long long* stamps;      // tools/ build only: 16 phase stamps per workgroup
-#endif
     int B, N, H;
     float scale;
 };
@@ -263,13 +260,8 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     constexpr int NT = NP / 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef NRV_SK_STAMPS      // tools/build_dev.py only: phase stamps of wave 0
-    unsigned long long* stamp_out = p.stamps + (long long)blockIdx.x * 16;
-    int stamp_i = 0;
-#define SK_STAMP() do { if (tid == 0) stamp_out[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
-#else
-#define SK_STAMP() do { } while (0)
-#endif
+    NRV_STAMP_SEQ_VARS(tid);      // phase stamps of thread 0: empty hooks in the product (csrc/nrv_dev.hpp)
+#define SK_STAMP() NRV_STAMP_SEQ()
     SK_STAMP();
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N;
@@ -598,7 +590,7 @@ int launch_sk_fwd(const SinkParams& p, hipStream_t s) {
 
 template <int NP>
 int launch_sk_bwd(const SinkParams& p, hipStream_t s) {
-    constexpr int TPW = NRV_SK_TPW;
+    constexpr int TPW = SK_TPW;
     constexpr int lds = SkBwdLds<NP, TPW>::BYTES;
     static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_kernel<NP, TPW>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -642,11 +634,6 @@ extern "C" int nrv_attn_sinkhorn_fwd(const void* qkv_bf16, void* out_bf16, float
     NRV_SK_DISPATCH(N, launch_sk_fwd<NPV>(p, s));
 }
 
-#ifdef NRV_SK_STAMPS
-static unsigned long long* g_sk_stamps = nullptr;
-extern "C" void nrv_dev_sinkhorn_stamp_buffer(void* p) { g_sk_stamps = static_cast<unsigned long long*>(p); }
-#endif
-
 extern "C" int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16, const float* lse, const float* scalings,
                                      void* dqkv_bf16, int B, int N, int H, int dh, float scale, void* stream) {
     if (!qkv_bf16 || !dout_bf16 || !lse || !scalings || !dqkv_bf16) return NRV_ERR_NULL;
@@ -657,10 +644,6 @@ extern "C" int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16
     p.dout = static_cast<const bf16_t*>(dout_bf16);
     p.dqkv = static_cast<bf16_t*>(dqkv_bf16);
     p.lse = const_cast<float*>(lse); p.scal = const_cast<float*>(scalings);
-#ifdef NRV_SK_STAMPS
-    if (!g_sk_stamps) return NRV_ERR_NULL;
-    p.stamps = g_sk_stamps;
-#endif
     p.B = B; p.N = N; p.H = H; p.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     NRV_SK_DISPATCH(N, launch_sk_bwd<NPV>(p, s));

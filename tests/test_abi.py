@@ -53,6 +53,45 @@ def test_product_has_no_environment_switches():
     assert hits == [], hits
 
 
+def test_product_sources_have_no_experiment_switches_and_empty_dev_hooks():
+    """The HIP sources carry no preprocessor conditionals (no experiment / instrumentation variant can be switched on with a
+    compiler flag); the only hook is <nrv_dev.hpp>, whose product version defines nothing but empty macros."""
+    csrc = os.path.join(ROOT, "noise_robust_vit_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".hpp")):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        assert not re.search(r"^\s*#\s*(ifdef|ifndef|if|elif|else)\b", code, flags=re.M), f"{fn}: conditional compilation"
+        if fn != "nrv_dev.hpp":
+            assert "s_memtime" not in code and "s_memrealtime" not in code, f"{fn}: clock read outside the dev hooks"
+    hooks = open(os.path.join(csrc, "nrv_dev.hpp")).read()
+    hooks = re.sub(r"//[^\n]*", "", hooks)
+    for line in hooks.splitlines():
+        line = line.strip()
+        if not line or line == "#pragma once":
+            continue
+        m = re.match(r"#define\s+(NRV_[A-Z_]+)(\([^)]*\))?\s*(.*)$", line)
+        assert m, f"nrv_dev.hpp: unexpected line {line!r}"
+        assert m.group(3) in ("", "(choice)"), f"nrv_dev.hpp: hook {m.group(1)} is not empty: {m.group(3)!r}"
+
+
+def test_product_device_code_reads_no_clock(lib_path, tmp_path):
+    """Instrumented builds read s_memtime / s_memrealtime; the shipped device code must contain neither."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    import shutil
+    so = shutil.copy(lib_path, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], capture_output=True, text=True, cwd=tmp_path)
+    cos = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert cos, "no gfx950 code objects found in the library"
+    for f in cos:
+        dis = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+        assert "v_mfma" in dis or "buffer_" in dis or "global_" in dis      # really device code
+        assert "s_memtime" not in dis and "s_memrealtime" not in dis, f
+
+
 def test_loader_sets_prototypes_and_reports_errors(lib_path):
     from noise_robust_vit_amd import _lib
     lib = _lib.load()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Phase times of the Sinkhorn backward (wave 0 of every workgroup, s_memtime) from a -DNRV_SK_STAMPS developer build
-(`python tools/build_dev.py skst -DNRV_SK_STAMPS`).  GPU only; dev tool.   python tools/sinkhorn_stamps.py skst"""
+"""Phase times of the Sinkhorn backward (thread 0 of every workgroup, s_memtime) from an instrumented developer build
+(`python tools/build_dev.py stamps --instrument`).  GPU only; dev tool.   python tools/sinkhorn_stamps.py stamps"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
@@ -15,16 +15,17 @@ lib = _lib.load()
 o, lse, scal = K.attn_sinkhorn_fwd(qkv, B, N, H, 64, 0.125)
 dqkv = torch.empty_like(qkv)
 import ctypes
-ws = torch.zeros(B * H * 128, dtype=torch.uint8, device=dev)
-lib.nrv_dev_sinkhorn_stamp_buffer.argtypes = [ctypes.c_void_p]
-lib.nrv_dev_sinkhorn_stamp_buffer.restype = None
-lib.nrv_dev_sinkhorn_stamp_buffer(ws.data_ptr())
+import numpy as np
+lib.nrv_dev_read_stamps_sinkhorn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+assert lib.nrv_dev_stamps_enable_sinkhorn() == 0
 for _ in range(3):
     rc = lib.nrv_attn_sinkhorn_bwd(qkv.data_ptr(), do.data_ptr(), lse.data_ptr(), scal.data_ptr(), dqkv.data_ptr(),
                                    B, N, H, 64, 0.125, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 torch.cuda.synchronize()
-st = ws[:B * H * 128].view(torch.int64).view(B * H, 16).cpu()
+buf = np.zeros(B * H * 16, dtype=np.uint64)
+assert lib.nrv_dev_read_stamps_sinkhorn(buf.ctypes.data, buf.size) == 0
+st = torch.from_numpy(buf.astype(np.int64)).view(B * H, 16)
 names = ["images K/dO + vectors", "dV phase (P7 -> chunk -> MFMA)", "V image + G init", "t=3 row+col", "t=2 row+col", "t=1 row+col", "t=0 row",
          "softmax backward", "dQ", "Q image + dK phase"]
 tot = (st[:, 10] - st[:, 0]).double()
