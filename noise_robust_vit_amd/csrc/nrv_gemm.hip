@@ -539,7 +539,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 //     quadrant (A half i) x (B half j) of its block per PHASE.  A K-step is four phases:
 //         phase 0: read B0, A0 | quadrant (A0, B0)      phase 2: read A1 | quadrant (A1, B1)
 //         phase 1: read B1     | quadrant (A0, B1)      phase 3: --      | quadrant (A1, B0)   (B0 stays in registers)
-//     each phase = [fragment reads + ONE half-tile of LDS-DMA + counted vmcnt] s_barrier [MFMAs under s_setprio 1] s_barrier.
+//     each phase = [fragment reads + ONE half-tile of LDS-DMA + counted vmcnt] s_barrier [MFMAs] s_barrier.
 //   * Waves 4-7 (wave row 1; the SIMD partners of waves 0-3) run ONE barrier behind waves 0-3: on every SIMD one wave is in
 //     its MFMA section while the other reads fragments and issues DMA.
 //   * Half-tile op n = 4 t + {A0, B0, B1, A1} of K-step t is issued in global phase n - 6 (a half is re-staged >= 2 phases
@@ -706,7 +706,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0), through the builtin: hipcc's own counter restarts at 0
         NRV_WACC(4 * P + 2);                                      // section 2: barrier + fragment-read latency
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
         constexpr int mh = (P >= 2) ? MH : 0;                    // first row tile of the quadrant
         constexpr int nh = (P == 1 || P == 2) ? 2 : 0;           // first column tile
 #pragma unroll
@@ -716,7 +715,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
 #pragma unroll
                 for (int nl = 0; nl < 2; ++nl)
                     acc[mh + ml][nh + nl] = mfma16((P == 1 || P == 2) ? b1[nl][ks] : b0[nl][ks], a[ml][ks], acc[mh + ml][nh + nl]);
-        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         NRV_WACC(4 * P + 3);                                      // section 3: MFMA section + closing barrier
@@ -985,7 +983,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     constexpr int AH = BK * RAH, BH = BK * RBH, STG = 2 * AH + 2 * BH;
     constexpr int NA = AH / 8192, NB = BH / 8192;             // DMA instructions per wave and half-tile op
     static_assert(AH % 8192 == 0 && BH % 8192 == 0 && RAH % 256 == 0 && RBH % 256 == 0, "whole pieces, rows of 8 units");
-    constexpr int W4 = 2 * NA + 2 * NB;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1080,113 +1077,132 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t a[MH][2], b0[2][2], b1[2][2];
+    bf16x8_t a[MH][2], bs[2][2][2];            // as in gemm_nt8_kernel: bs[q] / bs[q ^ 1] = B0 / B1 of a K-step of parity q
 
     // fused bias gradient db[m] = sum_t A[t, m] = (ones . A) on the MFMA, first column tile only; wave column wc takes the row
     // blocks 2 wc, 2 wc + 1 of its wave row: half wc >> 1, fragments (wc & 1) * MH / 2 + {0, 1}
     static_assert(MH == 4, "bias-gradient block assignment");
     const bool do_bias = p.bias_ws != nullptr && tn == 0;
     const u32x4_t ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
+    bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
     f32x4_t accb[2];
     accb[0] = accb[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    auto phase = [&](auto P_c, auto ST_c, auto WAIT_c, int kt) {
-        constexpr int P = decltype(P_c)::value;
-        constexpr bool ST = decltype(ST_c)::value;
+    // the phase of gemm_nt8_kernel (reads: A0 | B1 | A1 | next B0; ops: A1 (kt + 1) | B0 | A0 | B1 (kt + 2); five phases of flight)
+    auto phase = [&](auto P_c, auto PAR_c, auto ST_c, auto WAIT_c, auto RD_c, auto MF_c, int kt) {
+        constexpr int P = decltype(P_c)::value, PAR = decltype(PAR_c)::value;
+        constexpr bool ST = decltype(ST_c)::value, RD = decltype(RD_c)::value, MF = decltype(MF_c)::value;
         constexpr int WAIT = decltype(WAIT_c)::value;
-        if constexpr (P == 0) {
+        if constexpr (P == 3 && MF) next_stage();
+        if constexpr (RD) {
+            if constexpr (P == 0) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int nl = 0; nl < 2; ++nl) b0[nl][ks] = ld_b(0, nl, ks);
+                    for (int ml = 0; ml < MH; ++ml) a[ml][ks] = ld_a(0, ml, ks);
+            } else if constexpr (P == 1) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = ld_a(0, ml, ks);
-        } else if constexpr (P == 1) {
+                    for (int nl = 0; nl < 2; ++nl) bs[PAR ^ 1][nl][ks] = ld_b(1, nl, ks);
+            } else if constexpr (P == 2) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int nl = 0; nl < 2; ++nl) b1[nl][ks] = ld_b(1, nl, ks);
-        } else if constexpr (P == 2) {
+                    for (int ml = 0; ml < MH; ++ml) a[ml][ks] = ld_a(1, ml, ks);
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ml = 0; ml < MH; ++ml) a[ml][ks] = ld_a(1, ml, ks);
+                    for (int nl = 0; nl < 2; ++nl) bs[PAR ^ 1][nl][ks] = ld_b(0, nl, ks);
+            }
         }
         if constexpr (ST) {
-            if constexpr (P == 0) stage(I2{}, kt + 1);
-            else if constexpr (P == 1) stage(I3{}, kt + 1);
+            if constexpr (P == 0) stage(I3{}, kt + 1);
+            else if constexpr (P == 1) stage(I1{}, kt + 2);
             else if constexpr (P == 2) stage(I0{}, kt + 2);
-            else stage(I1{}, kt + 2);
+            else stage(I2{}, kt + 2);
         }
         if constexpr (WAIT >= 0) wait_vm<WAIT>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        constexpr int mh = (P >= 2) ? MH : 0;
-        constexpr int nh = (P == 1 || P == 2) ? 2 : 0;
+        if constexpr (MF) {
+            constexpr int mh = (P >= 2) ? MH : 0;
+            constexpr int nh = (P == 1 || P == 2) ? 2 : 0;
+            constexpr int bq = (P == 1 || P == 2) ? (PAR ^ 1) : PAR;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ml = 0; ml < MH; ++ml)
+                for (int ml = 0; ml < MH; ++ml)
 #pragma unroll
-                for (int nl = 0; nl < 2; ++nl)
-                    acc[mh + ml][nh + nl] = mfma16((P == 1 || P == 2) ? b1[nl][ks] : b0[nl][ks], a[ml][ks], acc[mh + ml][nh + nl]);
-        if constexpr (P == 0 || P == 2) {
-            if (do_bias && (wc >> 1) == P / 2) {              // uniform
-                if (wc & 1) {
+                    for (int nl = 0; nl < 2; ++nl)
+                        acc[mh + ml][nh + nl] = mfma16(bs[bq][nl][ks], a[ml][ks], acc[mh + ml][nh + nl]);
+            if constexpr (P == 0 || P == 2) {
+                if (do_bias && (wc >> 1) == P / 2) {              // uniform
+                    if (wc & 1) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, a[2 + j][ks], accb[j]);
-                } else {
+                            for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, a[2 + j][ks], accb[j]);
+                    } else {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, a[j][ks], accb[j]);
+                            for (int j = 0; j < 2; ++j) accb[j] = mfma16(ones, a[j][ks], accb[j]);
+                    }
                 }
             }
         }
-        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
     using T = std::true_type; using F = std::false_type;
     using WN_ = std::integral_constant<int, -1>;
-    using WF = std::integral_constant<int, W4>;
-    using WT2 = std::integral_constant<int, NB + NA>;
-    using WT1 = std::integral_constant<int, NA>;
+    using WE = std::integral_constant<int, 3 * NA + 2 * NB>;        // windows of the five youngest ops (gemm_nt8_kernel)
+    using WO = std::integral_constant<int, 2 * NA + 3 * NB>;
+    using WT1 = std::integral_constant<int, 2 * NA + 2 * NB>;
+    using WT2 = std::integral_constant<int, 2 * NA + NB>;
+    using WT3 = std::integral_constant<int, NB + NA>;
+    using WL0 = std::integral_constant<int, NA>;
     using W0 = std::integral_constant<int, 0>;
+    auto kstep = [&](auto PAR_c, int kt) {
+        phase(I0{}, PAR_c, T{}, WE{}, T{}, T{}, kt);
+        phase(I1{}, PAR_c, T{}, WO{}, T{}, T{}, kt);
+        phase(I2{}, PAR_c, T{}, WE{}, T{}, T{}, kt);
+        phase(I3{}, PAR_c, T{}, WO{}, T{}, T{}, kt);
+    };
 
-    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0); stage(I0{}, 1); stage(I1{}, 1);
-    wait_vm<W4>();
+    stage(I1{}, 0); stage(I0{}, 0); stage(I2{}, 0); stage(I3{}, 0); stage(I1{}, 1); stage(I0{}, 1); stage(I2{}, 1);
+    wait_vm<3 * NA + 3 * NB>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
+    const int nmain = nk - 2;
     int kt = 0;
-    for (; kt < nk - 2; ++kt) {
-        phase(I0{}, T{}, WF{}, kt);
-        phase(I1{}, T{}, WF{}, kt);
-        phase(I2{}, T{}, WN_{}, kt);
-        phase(I3{}, T{}, WF{}, kt);
-        next_stage();
+    if (nmain & 1) {
+        phase(I3{}, I0{}, F{}, WO{}, T{}, F{}, -1);
+        kstep(I1{}, 0);
+        kt = 1;
+    } else {
+        phase(I3{}, I1{}, F{}, WO{}, T{}, F{}, -1);
     }
-    phase(I0{}, T{}, WF{}, kt);
-    phase(I1{}, T{}, WF{}, kt);
-    phase(I2{}, F{}, WN_{}, kt);
-    phase(I3{}, F{}, WT2{}, kt);
-    next_stage();
+    for (; kt < nmain; kt += 2) {
+        kstep(I0{}, kt);
+        kstep(I1{}, kt + 1);
+    }
+    phase(I0{}, I0{}, T{}, WE{}, T{}, T{}, kt);
+    phase(I1{}, I0{}, F{}, WT1{}, T{}, T{}, kt);
+    phase(I2{}, I0{}, F{}, WT2{}, T{}, T{}, kt);
+    phase(I3{}, I0{}, F{}, WT3{}, T{}, T{}, kt);
     ++kt;
-    phase(I0{}, F{}, WT1{}, kt);
-    phase(I1{}, F{}, W0{}, kt);
-    phase(I2{}, F{}, WN_{}, kt);
-    phase(I3{}, F{}, WN_{}, kt);
+    phase(I0{}, I1{}, F{}, WL0{}, T{}, T{}, kt);
+    phase(I1{}, I1{}, F{}, W0{}, T{}, T{}, kt);
+    phase(I2{}, I1{}, F{}, WN_{}, T{}, T{}, kt);
+    phase(I3{}, I1{}, F{}, WN_{}, F{}, T{}, kt);
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
     if (do_bias && lane < 16) {
@@ -1198,7 +1214,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     }
     EpiParams e = p.e;
     e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
-    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, smem, e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane, wave);
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));            // keeps the epilogue's per-lane address arithmetic below the K loop
+    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, smem, e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane_e, wave);
 }
 
 // C = beta * C + sum_s slab[s].  A block of 4 waves owns 64 consecutive 16-byte chunks of C; wave g sums the slabs
