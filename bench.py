@@ -34,7 +34,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r02"
+ROUND = "r03"
 
 
 def _vit(L, H, D, M):
@@ -54,8 +54,10 @@ ARCHS = {
     "simplevit_s_16": ("simple", _simple(12, 6, 384, 1536), 27.444),
     "simplevit_l_16": ("simple", _simple(24, 16, 1024, 4096), 367.400),
     # MAE (mae.py:9-49): lucidrains-style ViT-B/16 encoder on the 49 kept tokens + the wrapper's default decoder (512 wide, 1 layer,
-    # 8 heads) on all 196.  25.935 = BASELINE.md's encoder-only figure (the decoder and the two projections add 4.4 GFLOP/img)
-    "mae_b_16": ("mae", dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072), 25.935),
+    # 8 heads) on all 196.  30.333 = BASELINE.md's encoder-only 25.935 (patch embedding on 196 tokens + 12 blocks on 49) + the
+    # work the step also does: enc_to_dec 49 x 768 x 512, one decoder block at 196 tokens (qkv 512 -> 1536, out 512 -> 512,
+    # QK^T / PV 8 heads x 64, MLP 512 -> 2048 -> 512) and to_pixels 147 x 512 x 768 = 1.465 GFLOP forward, x 3 for the step
+    "mae_b_16": ("mae", dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072), 30.333),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0
@@ -192,6 +194,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel-class time table to stderr")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient exchange precision (N > 1)")
+    ap.add_argument("--bucket-mib", type=float, default=64.0, help="all-reduce bucket size")
+    ap.add_argument("--tail-mib", type=float, default=8.0, help="cap of the last (non-overlappable) bucket")
+    ap.add_argument("--rccl-max-ctas", type=int, default=0, help="CU budget of RCCL's kernels (0: RCCL default)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (Trainer.capture)")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # started by torch.distributed.run
@@ -209,21 +216,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    from noise_robust_vit_amd import kernels as K
+    from noise_robust_vit_amd.parallel import GradReducer, make_process_group
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
     use_pg = world > 1 or launched
+    pg_desc = ""
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" IS RCCL on ROCm
-
-    from noise_robust_vit_amd import kernels as K
-    from noise_robust_vit_amd.parallel import GradReducer
-    from noise_robust_vit_amd.train import TrainConfig, Trainer
+        pg_desc = make_process_group(rank, world, device=dev, backend="nccl", max_ctas=args.rccl_max_ctas)   # "nccl" IS RCCL on ROCm
 
     kind = ARCHS[args.arch][0]
     batch = args.batch or (128 if args.arch.endswith("l_16") else 256)
     model = build_model(args.arch, robust=args.robust).to(dev).train()
     # under the launcher the collectives are issued at any world size (world 1: a one-rank RCCL group, same calls)
-    reducer = GradReducer(model, world, force_collectives=world == 1) if use_pg else None
+    reducer = GradReducer(model, world, force_collectives=world == 1, bucket_mib=args.bucket_mib, tail_mib=args.tail_mib,
+                          grad_dtype=args.grad_dtype) if use_pg else None
     compute_loss = (lambda m, xb, yb: m(xb)) if kind == "mae" else None
     trainer = Trainer(model, TrainConfig(lr=5e-4, weight_decay=0.05, grad_max_norm=5.0, noise_std=args.noise_std), reducer,
                       compute_loss=compute_loss)
@@ -275,7 +283,9 @@ def main():
                    "parallelism": f"dp{world}",
                    "step": ("fwd + MSE on masked patches" if kind == "mae" else "fwd + CE(ls=0.1)") + " + bwd + allreduce + clip(5.0) + AdamW",
                    "collectives": ("none (single process, no process group)" if not use_pg else
-                                   "rccl all_reduce(AVG) per 64 MiB bucket" + (", forced at world 1" if world == 1 else ", overlapped with backward")),
+                                   f"rccl all_reduce(AVG) of {args.grad_dtype} gradients per {args.bucket_mib:g} MiB bucket (last bucket <= "
+                                   f"{args.tail_mib:g} MiB; buckets {[round(b / 2**20, 1) for b in reducer.bucket_bytes()]} MiB); {pg_desc}"
+                                   + (", forced at world 1" if world == 1 else ", overlapped with backward")),
                    "residual_stream": "fp32", "gemm_operands": "bf16", "accumulate": "fp32",
                    "timing": f"{args.warmup} warm-up + {args.steps} timed steps, barrier + synchronize on both sides; "
                              "ms_per_step_median = median of per-step HIP-event spans on the compute stream"},

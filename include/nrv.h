@@ -164,7 +164,8 @@ int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16, const flo
 /* ------------------------------------------------------------------------------------------
  * Patch unfold (replaces einops Rearrange 'b c (h p1) (w p2) -> b h w (p1 p2 c)' simple_vit.py:126-129,
  * and the im2col implied by Conv2d(k=s=p) vit.py:237-242,323).
- *   img [B,C,H,W] (img_dtype fp32|bf16) -> patches bf16 [B*(H/p)*(W/p), C*p*p]
+ *   img [B,C,H,W] (img_dtype fp32|bf16) -> patches bf16 [B*(H/p)*(W/p), FP], FP = C*p*p rounded up to a multiple of 8
+ *   (the GEMM's K granularity); columns >= C*p*p are written as zero (vit_h_14, vit.py:512-519: p = 14, 588 -> 592)
  *   layout 0: feature order (p1, p2, c)   [SimpleViT Linear weight order]
  *   layout 1: feature order (c, p1, p2)   [Conv2d weight.reshape(D,-1) order]
  * ---------------------------------------------------------------------------------------- */

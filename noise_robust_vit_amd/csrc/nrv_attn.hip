@@ -24,6 +24,13 @@
 
 #include "nrv_attn_common.hpp"
 
+// nrv_attn_gen.hip: streaming kernels for the shapes the single-pass kernels below do not hold on chip (N > 256, dh != 64)
+NRV_INTERNAL int nrv_attn_gen_supported(int B, int N, int H, int dh);
+NRV_INTERNAL int nrv_attn_gen_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, hipStream_t s);
+NRV_INTERNAL int nrv_attn_gen_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
+                     int B, int N, int H, int dh, float scale, hipStream_t s);
+NRV_INTERNAL int nrv_attn_gen_probs(const void* qkv, const float* lse, float* probs, int B, int N, int H, int dh, float scale, hipStream_t s);
+
 namespace {
 
 using namespace nrv_attn;
@@ -618,11 +625,12 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
     }
 }
 
-int check_shape(int B, int N, int H, int dh) {
-    if (B <= 0 || N <= 0 || H <= 0) return NRV_ERR_SHAPE;
-    if (dh != DH || N > 256) return NRV_ERR_SHAPE;
-    if ((long long)B * H > 0x7fffffffll) return NRV_ERR_SHAPE;
-    return 0;
+// shape class of a call: 1 = the single-pass kernels of this file (dh 64, N <= 256), 2 = the streaming kernels of
+// nrv_attn_gen.hip (any N, dh 32 / 64 / 80 / 96 / 128), 0 = not supported
+int shape_class(int B, int N, int H, int dh) {
+    if (B <= 0 || N <= 0 || H <= 0) return 0;
+    if (dh == DH && N <= 256) return (long long)B * H > 0x7fffffffll ? 0 : 1;
+    return nrv_attn_gen_supported(B, N, H, dh) ? 2 : 0;
 }
 
 }  // namespace
@@ -630,8 +638,10 @@ int check_shape(int B, int N, int H, int dh) {
 extern "C" int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
                             int B, int N, int H, int dh, float scale, void* stream) {
     if (!qkv_bf16 || !out_bf16 || !lse) return NRV_ERR_NULL;
-    if (int e = check_shape(B, N, H, dh)) return e;
+    const int cls = shape_class(B, N, H, dh);
+    if (cls == 0) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(qkv_bf16) || !nrv_aligned16(out_bf16)) return NRV_ERR_ALIGN;
+    if (cls == 2) return nrv_attn_gen_fwd(qkv_bf16, out_bf16, lse, B, N, H, dh, scale, static_cast<hipStream_t>(stream));
     AttnParams p{};
     p.qkv = static_cast<const bf16_t*>(qkv_bf16);
     p.o = static_cast<bf16_t*>(out_bf16);
@@ -645,9 +655,12 @@ extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const vo
                             void* dqkv_bf16, float* delta_ws,
                             int B, int N, int H, int dh, float scale, void* stream) {
     if (!qkv_bf16 || !out_bf16 || !dout_bf16 || !lse || !dqkv_bf16 || !delta_ws) return NRV_ERR_NULL;
-    if (int e = check_shape(B, N, H, dh)) return e;
+    const int cls = shape_class(B, N, H, dh);
+    if (cls == 0) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(qkv_bf16) || !nrv_aligned16(out_bf16) || !nrv_aligned16(dout_bf16) || !nrv_aligned16(dqkv_bf16))
         return NRV_ERR_ALIGN;
+    if (cls == 2)
+        return nrv_attn_gen_bwd(qkv_bf16, out_bf16, dout_bf16, lse, dqkv_bf16, delta_ws, B, N, H, dh, scale, static_cast<hipStream_t>(stream));
     AttnParams p{};
     p.qkv = static_cast<const bf16_t*>(qkv_bf16);
     p.out = static_cast<const bf16_t*>(out_bf16);
@@ -663,9 +676,11 @@ extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const vo
 extern "C" int nrv_attn_probs(const void* qkv_bf16, const float* lse, float* probs,
                               int B, int N, int H, int dh, float scale, void* stream) {
     if (!qkv_bf16 || !lse || !probs) return NRV_ERR_NULL;
-    if (int e = check_shape(B, N, H, dh)) return e;
+    const int cls = shape_class(B, N, H, dh);
+    if (cls == 0) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(qkv_bf16)) return NRV_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (cls == 2) return nrv_attn_gen_probs(qkv_bf16, lse, probs, B, N, H, dh, scale, s);
     hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)(B * H), (unsigned)((N + 15) / 16)), dim3(256), 0, s,
                        static_cast<const bf16_t*>(qkv_bf16), lse, probs, B, N, H, scale);
     NRV_CHECK_LAUNCH();

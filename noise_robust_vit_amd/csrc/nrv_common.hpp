@@ -8,6 +8,7 @@
 #include "nrv.h"
 
 #define NRV_WAVE 64
+#define NRV_INTERNAL __attribute__((visibility("hidden")))     // cross-file helpers: not part of the C ABI
 
 typedef unsigned short bf16_t;                                    // raw bfloat16 storage
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;       // one MFMA 16x16x32 A/B fragment (4 VGPRs)

@@ -19,7 +19,7 @@ template <bool IMG_F32, int LAYOUT>
 __global__ __launch_bounds__(256) void patch_unfold_kernel(const void* __restrict__ img, bf16_t* __restrict__ out,
                                                            int B, int C, int H, int W, int p) {
     const int hh = H / p, ww = W / p;
-    const int F = C * p * p, F8 = F >> 3;
+    const int F = C * p * p, FP = (F + 7) & ~7, F8 = FP >> 3;      // rows are FP wide: features >= F (p = 14: 588 -> 592) are zero
     const long long total = (long long)B * hh * ww * F8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long t = i / F8;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(const void* __restric
             const int pp = f0 - c * p * p;
             const int p1 = pp / p, p2 = pp - p1 * p;
             const long long src = (((long long)b * C + c) * H + (py * p + p1)) * W + px * p + p2;
-            *reinterpret_cast<u32x4_t*>(out + t * F + f0) = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(img) + src);
+            *reinterpret_cast<u32x4_t*>(out + t * FP + f0) = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(img) + src);
             continue;
         }
         float v[8];
@@ -52,10 +52,10 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(const void* __restric
                 p1 = pp / p;
                 p2 = pp - p1 * p;
             }
-            v[j] = ld_img<IMG_F32>(img, (((long long)b * C + c) * H + (py * p + p1)) * W + px * p + p2);
+            v[j] = f < F ? ld_img<IMG_F32>(img, (((long long)b * C + c) * H + (py * p + p1)) * W + px * p + p2) : 0.f;
         }
         u32x4_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        *reinterpret_cast<u32x4_t*>(out + t * F + f0) = pk;
+        *reinterpret_cast<u32x4_t*>(out + t * FP + f0) = pk;
     }
 }
 
@@ -224,12 +224,12 @@ extern "C" const char* nrv_error_string(int code) {
 extern "C" int nrv_patch_unfold(const void* img, int img_dtype, void* patches_bf16,
                                 int B, int C, int H, int W, int p, int layout, void* stream) {
     if (!img || !patches_bf16) return NRV_ERR_NULL;
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p || ((C * p * p) & 7)) return NRV_ERR_SHAPE;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p) return NRV_ERR_SHAPE;
     if (img_dtype != NRV_F32 && img_dtype != NRV_BF16) return NRV_ERR_DTYPE;
     if (layout != NRV_PATCH_P1P2C && layout != NRV_PATCH_CP1P2) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(patches_bf16)) return NRV_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long total = (long long)B * (H / p) * (W / p) * ((C * p * p) >> 3);
+    const long long total = (long long)B * (H / p) * (W / p) * ((C * p * p + 7) >> 3);
     const int grid = grid_for(total, 256);
     bf16_t* out = static_cast<bf16_t*>(patches_bf16);
     if (img_dtype == NRV_F32) {

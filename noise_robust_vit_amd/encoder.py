@@ -433,7 +433,15 @@ class PatchEmbedFn(torch.autograd.Function):
         n = (H // patch) * (W // patch)
         D = weight.shape[0]
         patches = K.patch_unfold(img.detach(), patch, layout)
-        wb, _ = WEIGHTS.get(weight, False)
+        F, FP = C * patch * patch, patches.shape[1]
+        if FP == F:
+            wb, _ = WEIGHTS.get(weight, False)
+        else:
+            # patch sizes whose feature count is not a multiple of 8 (vit_h_14: 3 * 14 * 14 = 588): the unfold kernel pads the
+            # rows with zero columns to the GEMM's K granularity; the projection gets matching zero columns (one small cast
+            # per forward, outside the weight cache -- no BASELINE config takes this path)
+            w2 = torch.nn.functional.pad(weight.detach().reshape(weight.shape[0], -1).to(torch.float32), (0, FP - F))
+            wb, _ = K.cast_transpose(w2, need_t=False)
         cls_slot = 0 if cls_token is None else 1
         S = n + cls_slot
         out = torch.empty(Bn * S, D, dtype=torch.float32, device=img.device)
@@ -466,10 +474,17 @@ class PatchEmbedFn(torch.autograd.Function):
         tw, bw = (sink.target(weight) if sink is not None else (None, 0.0))
         if tw is not None:
             tw = tw.reshape(D, -1)
+        F = weight[0].numel()
+        padded = patches.shape[1] != F               # zero feature columns (patch size 14): gradient of the real columns only
+        tgt = None if padded else tw
         if cls_slot:
-            dw = K.gemm_tn(d16, patches, out=tw, beta=bw, a_group=n, a_group_stride=S, a_row_offset=1, T=Bn * n)
+            dw = K.gemm_tn(d16, patches, out=tgt, beta=0.0 if padded else bw, a_group=n, a_group_stride=S, a_row_offset=1, T=Bn * n)
         else:
-            dw = K.gemm_tn(d16, patches, out=tw, beta=bw)
+            dw = K.gemm_tn(d16, patches, out=tgt, beta=0.0 if padded else bw)
+        if padded:
+            dw = dw[:, :F]
+            if tw is not None:
+                tw.copy_(dw) if bw == 0.0 else tw.add_(dw)
         # positional-table / class-token / bias gradients are reductions of dy over the batch
         dpos = dcls = db = None
         if pos_grad or cls_grad or cls_slot:

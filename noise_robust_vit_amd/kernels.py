@@ -318,11 +318,12 @@ def attn_sinkhorn_bwd(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: i
 
 
 def patch_unfold(img: Tensor, p: int, layout: int) -> Tensor:
-    """img [B,C,H,W] fp32|bf16 -> patches bf16 [B*(H/p)*(W/p), C*p*p]."""
+    """img [B,C,H,W] fp32|bf16 -> patches bf16 [B*(H/p)*(W/p), FP]; FP = C*p*p rounded up to a multiple of 8, the extra
+    columns are zero (only patch sizes like 14 have any)."""
     _dev(img, "img")
     img = img.contiguous()
     B, C, H, W = img.shape
-    out = torch.empty(B * (H // p) * (W // p), C * p * p, dtype=torch.bfloat16, device=img.device)
+    out = torch.empty(B * (H // p) * (W // p), (C * p * p + 7) // 8 * 8, dtype=torch.bfloat16, device=img.device)
     lib = _lib.load()
     _run("patch_unfold", 0.0, img.numel() * (img.element_size() + 2),
          lambda: lib.nrv_patch_unfold(img.data_ptr(), _dt(img, "img"), out.data_ptr(), B, C, H, W, p, layout, _stream()),
@@ -343,10 +344,16 @@ def cast_transpose(w: Tensor, need_t: bool = True):
     return wb, wt
 
 
-def cast_bf16(x: Tensor) -> Tensor:
+def cast_bf16(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     _f32(x, "x")
     x = x.contiguous()
-    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    else:
+        _bf16(out, "out")
+        if out.numel() != x.numel() or not out.is_contiguous():
+            raise NrvError("cast_bf16: out must be contiguous bf16 of the same size")
+        y = out
     lib = _lib.load()
     _run("cast_bf16", 0.0, x.numel() * 6,
          lambda: lib.nrv_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "nrv_cast_f32_bf16")

@@ -88,7 +88,11 @@ class Attention(nn.Module):
                     and wq.untyped_storage().data_ptr() == wkv.untyped_storage().data_ptr()
                     and wkv.data_ptr() == wq.data_ptr() + wq.numel() * 4)
         if adjacent:
-            key = ("view", wq.data_ptr(), wkv.data_ptr())
+            # the versions are part of the key: an in-place write to the parameters (load_state_dict, p.copy_()) bumps THEIR
+            # counters, not the counter of a separate tensor over the same storage, and the weight cache is keyed on
+            # (owner, version) -- a fresh tensor object makes it miss and re-stage the bf16 images.  (Updates through raw
+            # pointers by optim.FusedAdamW leave the versions alone and are followed by WEIGHTS.refresh_all().)
+            key = ("view", wq.data_ptr(), wkv.data_ptr(), wq._version, wkv._version)
             if self._fused_key != key:
                 # a tensor of its own over the same storage (not a view with a `_base`: the weight cache tracks owners)
                 self._fused = torch.empty(0, dtype=torch.float32, device=wq.device).set_(

@@ -57,7 +57,10 @@ class FusedAdamW:
         if max_norm and max_norm > 0:
             K.sumsq(self.grad, self.gnorm_sq, self._ws)
         # parameters without a gradient this step are skipped like torch.optim.AdamW skips `p.grad is None` (no weight decay,
-        # no moment update): the flat buffers are walked in the ranges between their slots (normally ONE range)
+        # no moment update): the flat buffers are walked in the ranges between their slots (normally ONE range).  Single
+        # process only -- with a process group every parameter steps (parallel.GradReducer.finish_step).  The bias
+        # correction uses the optimizer's global step count; torch keeps a per-parameter count, which differs only for a
+        # parameter that skipped steps.
         for lo, hi in self._active_ranges():
             K.adamw_flat(self.param[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                          self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
@@ -84,11 +87,33 @@ class FusedAdamW:
         """Global gradient norm seen by the last clipped step (device scalar; reading it synchronises)."""
         return self.gnorm_sq.sqrt()
 
+    def _layout(self):
+        """[(offset, numel)] of every parameter in registration order: what the flat moment buffers mean."""
+        return [tuple(self.reducer.slot(p)) for p in self.reducer.parameters()]
+
     def state_dict(self) -> dict:
         return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "layout": self._layout(),
                 "lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}
 
     def load_state_dict(self, sd: dict) -> None:
+        """The moments are flat buffers in the reducer's slot order, which depends on `grad_groups()` and on the build that
+        wrote the checkpoint: the saved slot table is compared with this optimizer's and the moments are re-laid out per
+        parameter when it differs (same parameters in the same registration order, other offsets); anything else raises."""
+        mine, theirs = self._layout(), sd.get("layout")
+        if theirs is None:
+            if sd["exp_avg"].numel() != self.exp_avg.numel():
+                raise NrvError("optimizer state without a slot table and of another size: cannot be loaded")
+            theirs = mine           # checkpoints written before the table existed: same build, same layout
+        theirs = [tuple(t) for t in theirs]
+        if len(theirs) != len(mine) or any(a[1] != b[1] for a, b in zip(mine, theirs)):
+            raise NrvError("optimizer state belongs to another parameter set (count or sizes differ)")
         self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if theirs == mine and sd["exp_avg"].numel() == self.exp_avg.numel():
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        src_m, src_v = sd["exp_avg"].to(self.exp_avg.device), sd["exp_avg_sq"].to(self.exp_avg.device)
+        for (o, n), (so, sn) in zip(mine, theirs):
+            self.exp_avg[o:o + n].copy_(src_m[so:so + sn])
+            self.exp_avg_sq[o:o + n].copy_(src_v[so:so + sn])

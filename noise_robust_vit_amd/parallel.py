@@ -16,7 +16,12 @@ encoder path produces gradients:
     messages (default 64 MiB) rather than NVSwitch-style many small ones -- ring all-reduce on a fully
     connected 8-GPU xGMI mesh is per-link bound, so fewer, larger collectives amortise the launch and
     keep every link streaming;
-  * `finish_step()` waits for all collectives (compute stream waits on the RCCL stream) before clip + AdamW.
+  * `finish_step()` waits for all collectives (compute stream waits on the RCCL stream) before clip + AdamW;
+  * knobs sized for xGMI (7 point-to-point links x ~153 GB/s per GPU, ring collectives per-link bound): `grad_dtype="bf16"`
+    halves the bytes on the links (ViT-B/16: 173 instead of 346 MB per step; each bucket is cast into a bf16 staging slab by
+    nrv_cast_f32_bf16, reduced, and converted back into the fp32 buffer the optimizer reads), `tail_mib` caps the LAST
+    bucket in backward order (patch embedding / first layers: the only one with no backward work left to hide behind),
+    `make_process_group(..., max_ctas=...)` bounds the CUs RCCL's kernels may occupy next to GEMMs that hold every CU.
 
 Works with the `gloo` backend on CPU tensors too (tests/test_parallel_gloo.py): there all parameters are
 autograd-managed and averaging is SUM followed by a scale.
@@ -29,17 +34,49 @@ import torch
 import torch.distributed as dist
 
 
+def make_process_group(rank: int, world: int, device=None, backend: str = "nccl", max_ctas: int = 0, min_ctas: int = 0,
+                       high_priority_stream: bool = False, **kw):
+    """`dist.init_process_group` with the RCCL communicator's CU budget made explicit ("nccl" IS RCCL on ROCm).
+    `max_ctas` / `min_ctas` (0: RCCL's default) go into the communicator config (ncclConfig_t maxCTAs / minCTAs = the
+    workgroups = channels a collective may launch): the GEMMs of the backward occupy all 256 CUs with one workgroup each, so
+    every CU an all-reduce takes is a CU a GEMM round waits for; 8-16 workgroups keep a ring over 7 xGMI links busy.
+    Returns the options' description (for bench.py's `config.collectives`)."""
+    opts = None
+    desc = f"{backend} default communicator config"
+    if backend == "nccl" and (max_ctas or min_ctas or high_priority_stream):
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=bool(high_priority_stream))
+        if max_ctas:
+            opts.config.max_ctas = int(max_ctas)
+        if min_ctas:
+            opts.config.min_ctas = int(min_ctas)
+        desc = f"rccl max_ctas={max_ctas or 'default'} min_ctas={min_ctas or 'default'} high_priority_stream={bool(high_priority_stream)}"
+    args = dict(rank=rank, world_size=world, **kw)
+    if device is not None and backend == "nccl":
+        args["device_id"] = device
+    if opts is not None:
+        args["pg_options"] = opts
+    dist.init_process_group(backend, **args)
+    return desc
+
+
 class GradReducer:
     def __init__(self, model: torch.nn.Module, world: int, bucket_mib: float = 64.0,
                  process_group=None, attach: bool = True, sync_params: bool = True,
-                 force_collectives: bool = False) -> None:
+                 force_collectives: bool = False, grad_dtype: str = "fp32", tail_mib: float = 8.0) -> None:
         """`sync_params`: broadcast rank 0's parameters and buffers at construction, as DistributedDataParallel does
         (examples/CIFAR100.py:206-208 wraps the model in DDP): replicas start identical whatever each rank's seed was.
         `force_collectives`: issue every bucket's all-reduce even when world == 1 (a single-GPU RCCL process group
-        exercises exactly the calls, stream ordering and buffer slicing of the multi-GPU step)."""
+        exercises exactly the calls, stream ordering and buffer slicing of the multi-GPU step).
+        `grad_dtype`: "fp32" (default, exact mean of the ranks' fp32 gradients) or "bf16" (each rank's bucket is rounded to
+        bf16 before the reduction: 8 significant bits per addend, relative error of the mean <= 2^-8 per element -- the size of
+        the rounding the bf16 GEMM operands already carry; tests/test_parallel_gloo.py states the measured cost).
+        `tail_mib`: upper bound of the last bucket in backward order (0: no cap)."""
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
         self.world = world
         self.pg = process_group
         self.force = bool(force_collectives)
+        self.grad_dtype = grad_dtype
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
@@ -47,6 +84,10 @@ class GradReducer:
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
                     dist.broadcast(t.data, src=0, group=process_group)
+            # the broadcast writes through .data (no version bump): bf16 weight images staged by a forward that ran before
+            # this point (a sanity / warm-up forward on a rank != 0) would keep the pre-broadcast values
+            from .encoder import WEIGHTS
+            WEIGHTS.clear()
         # backward order: the reverse of registration order (head ... first encoder layer ... patch embed); parameters the
         # model wants back to back in a given order (`grad_groups()`: lucid_vit's to_q / to_kv, whose gradients are the row
         # blocks of ONE fused-projection GEMM) are placed as a unit where the first of them falls
@@ -89,6 +130,21 @@ class GradReducer:
                 cur_start, cur_ids = end, []
         if cur_ids:
             self.buckets.append((cur_start, total, cur_ids))
+        # The last bucket cannot overlap anything (its parameters are final when the backward ends): split it so that what
+        # is left after the split point is at most `tail_mib` -- the bulk goes out while the first layers' backward runs.
+        tail_cap = int(tail_mib * (1 << 20) / 4)
+        if tail_cap > 0 and self.buckets:
+            s0, e0, ids0 = self.buckets[-1]
+            if e0 - s0 > tail_cap and len(ids0) > 1:
+                k = len(ids0) - 1                          # at least the last parameter (it may be larger than the cap by itself)
+                for j in range(1, len(ids0)):
+                    if e0 - self._slot[ids0[j]][0] <= tail_cap:
+                        k = j
+                        break
+                cut = self._slot[ids0[k]][0]
+                self.buckets[-1] = (s0, cut, ids0[:k])
+                self.buckets.append((cut, e0, ids0[k:]))
+        self._stage_slabs: list = []
         self._bucket_of = {pid: b for b, (_, _, ids) in enumerate(self.buckets) for pid in ids}
         self._sink_managed: set = set()
         self._ready: set = set()
@@ -109,6 +165,8 @@ class GradReducer:
     def params_without_grad(self):
         """Parameters that received no gradient in the step just finished (valid between finish_step and begin_step):
         torch.optim.AdamW skips those entirely (no weight decay, no moment update), and so does optim.FusedAdamW."""
+        if self.world > 1:
+            return []          # decided identically on all ranks without a collective: see finish_step
         return [p for p in self._params if id(p) not in self._ready]
 
     def slot(self, p: torch.Tensor):
@@ -163,6 +221,18 @@ class GradReducer:
             return
         s, e, _ = self.buckets[b]
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
+        if self.grad_dtype == "bf16":
+            # one bf16 slab per bucket in flight (the staging tensors live until finish_step); cast on the compute stream,
+            # behind the kernels that produced the gradients, in front of the collective
+            slab = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+            if self.flat.is_cuda:
+                from . import kernels as K
+                K.cast_bf16(self.flat[s:e], out=slab)
+            else:
+                slab.copy_(self.flat[s:e])
+            self._stage_slabs.append((s, e, slab))
+            self._works.append(dist.all_reduce(slab, op=op, group=self.pg, async_op=True))
+            return
         self._works.append(dist.all_reduce(self.flat[s:e], op=op, group=self.pg, async_op=True))
 
     # ---- step protocol -----------------------------------------------------------------------
@@ -170,6 +240,7 @@ class GradReducer:
         self._ready = set()
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._stage_slabs = []
         # autograd accumulates (+=) into existing .grad views: clear the ones it manages
         for p in self._params:
             if id(p) not in self._sink_managed:
@@ -178,12 +249,24 @@ class GradReducer:
                     p.grad = self._views[id(p)]
 
     def finish_step(self) -> None:
-        for b in range(len(self.buckets)):          # parameters that received no gradient this step
+        # Parameters that received no gradient on THIS rank this step.  Their slots must not carry anything into the
+        # reduction or the clip norm: autograd-managed slots were zeroed in begin_step, kernel-written (sink-managed) slots
+        # still hold the previous step's gradient -- zero them now.  With world > 1 another rank may have used the parameter:
+        # the reduced gradient (this rank contributing zeros, DDP's find_unused_parameters semantics) is applied on EVERY
+        # rank, so replicas cannot diverge (`params_without_grad` is empty then); a parameter unused on every rank thus
+        # takes a zero-gradient AdamW step where torch.optim.AdamW would skip it -- the one documented difference.
+        for p in self._params:
+            if id(p) not in self._ready and id(p) in self._sink_managed:
+                self._views[id(p)].zero_()
+        for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
         for w in self._works:
             w.wait()
         self._works = []
+        for s, e, slab in self._stage_slabs:          # reduced bf16 means back into the fp32 buffer the optimizer reads
+            self.flat[s:e].copy_(slab)
+        self._stage_slabs = []
         if (self.world > 1 or self.force) and not self._avg_native and dist.is_initialized():
             self.flat.mul_(1.0 / self.world)
 

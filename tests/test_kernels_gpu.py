@@ -364,6 +364,58 @@ def test_attention_fwd_bwd(dev, B, N, H):
     assert cos > 0.9995, cos
 
 
+# streaming kernels (csrc/nrv_attn_gen.hip): N > 256 and head dims 32 / 64 / 80 / 96 / 128 -- vit_h_14 (16 heads x 80, 257 tokens,
+# vit.py:512-519), ViT-B/16 at 384 px after interpolate_embeddings (577 tokens), SimpleViT(dim_head=...); partial last tiles,
+# a single tile, N a multiple of the tile
+GEN_ATTN_SHAPES = [(2, 257, 16, 80), (2, 577, 12, 64), (1, 400, 3, 32), (1, 1024, 2, 128), (2, 300, 4, 96), (2, 100, 3, 32),
+                   (3, 64, 2, 128), (2, 197, 4, 80), (1, 1, 1, 96), (1, 320, 1, 64)]
+
+
+@pytest.mark.parametrize("B,N,H,dh", GEN_ATTN_SHAPES)
+def test_attention_streaming_any_n_and_head_dim(dev, B, N, H, dh):
+    k = _k()
+    scale = dh ** -0.5
+    qkv = rnd((B * N, 3 * H * dh), dev, 160, 1.0)
+    out, lse = k.attn_fwd(qkv, B, N, H, dh, scale)
+    qr = qkv.float().requires_grad_(True)
+    ref_o, ref_lse = attn_ref(qr, B, N, H, dh, scale)
+    assert (out.float() - ref_o).abs().max().item() < 2 ** -7 * ref_o.abs().max().item() + 1e-3, \
+        (out.float() - ref_o).abs().max().item()
+    assert (lse - ref_lse).abs().max().item() < 1e-4 * max(1.0, ref_lse.abs().max().item())
+    dout = rnd((B * N, H * dh), dev, 161, 1.0)
+    ref_o.backward(dout.float())
+    dqkv = k.attn_bwd(qkv, out, dout, lse, B, N, H, dh, scale)
+    err = (dqkv.float() - qr.grad).abs().max().item() / qr.grad.abs().max().item()
+    assert err < 2e-2, err
+    cos = torch.nn.functional.cosine_similarity(dqkv.float().reshape(-1), qr.grad.reshape(-1), dim=0).item()
+    assert cos > 0.9995, cos
+    # attention maps of the same shapes (Recorder export)
+    if N <= 400:
+        pm = k.attn_probs(qkv, lse, B, N, H, dh, scale)
+        q, kk, _ = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        ref = torch.softmax((q @ kk.transpose(-1, -2)) * scale, dim=-1)
+        assert (pm - ref).abs().max().item() < 2e-5
+
+
+def test_attention_streaming_online_rescale_is_exercised(dev):
+    """A rare-branch test (guide rule 26): the running maximum must JUMP at a chosen key tile.  One key far along the
+    sequence is aligned with every query, so that tiles before it are accumulated against a much smaller maximum and must be
+    rescaled by exp2(m_old - m_new) ~ 2^-60; checked against the full fp32 reference."""
+    k = _k()
+    B, N, H, dh = 1, 448, 2, 64
+    scale = 1.0
+    qkv = rnd((B * N, 3 * H * dh), dev, 162, 0.3)
+    v = qkv.view(B, N, 3, H, dh)
+    qdir = torch.nn.functional.normalize(torch.ones(dh, device=dev), dim=0)
+    v[:, :, 0] = (v[:, :, 0].float() + 3.0 * qdir).to(torch.bfloat16)          # every query has a component along qdir
+    v[:, 300, 1] = (14.0 * qdir).to(torch.bfloat16)                             # key 300 (tile 4 of 7): score ~ 42 above the rest
+    out, lse = k.attn_fwd(qkv, B, N, H, dh, scale)
+    ref_o, ref_lse = attn_ref(qkv, B, N, H, dh, scale)
+    assert torch.isfinite(out.float()).all()
+    assert (lse - ref_lse).abs().max().item() < 1e-3 * ref_lse.abs().max().item()
+    assert (out.float() - ref_o).abs().max().item() < 2 ** -6 * ref_o.abs().max().item() + 1e-3
+
+
 def test_attention_large_logits(dev):
     """softmax stability: scores of magnitude ~100 must not overflow (max subtraction)."""
     k = _k()
@@ -427,6 +479,13 @@ def test_patch_unfold(dev, layout, dt):
         ref = t.permute(0, 2, 4, 1, 3, 5)        # b h w c p1 p2  (Conv2d weight order)
     ref = ref.reshape(B * (H // p) * (W // p), C * p * p).to(torch.bfloat16)
     assert torch.equal(out, ref)
+    # patch size 14 (vit_h_14, vit.py:512-519): 3 * 14 * 14 = 588 features, rows padded to 592 with zero columns
+    p = 14
+    img = rnd((2, 3, 56, 42), dev, 71, 1.0, dt)
+    out = k.patch_unfold(img, p, layout)
+    t = img.reshape(2, 3, 4, p, 3, p)
+    ref = (t.permute(0, 2, 4, 3, 5, 1) if layout == 0 else t.permute(0, 2, 4, 1, 3, 5)).reshape(2 * 4 * 3, 588).to(torch.bfloat16)
+    assert out.shape == (24, 592) and torch.equal(out[:, :588], ref) and (out[:, 588:] == 0).all()
 
 
 @pytest.mark.parametrize("R,C", [(192, 576), (768, 3072), (100, 72), (1000, 192), (37, 50), (64, 64), (130, 6), (3, 257)])
@@ -462,9 +521,12 @@ def test_errors_are_loud(dev):
         k.gemm_nt(A, A)
     with pytest.raises(NrvError):
         k.gemm_nt(A.cpu(), A.cpu())     # CPU tensors are refused, not silently computed
+    qkv = rnd((300, 3 * 72), dev, 2)
+    with pytest.raises(NrvError):
+        k.attn_fwd(qkv, 1, 300, 1, 72, 0.125)   # head dim outside 32 / 64 / 80 / 96 / 128
     qkv = rnd((300, 3 * 64), dev, 2)
     with pytest.raises(NrvError):
-        k.attn_fwd(qkv, 1, 300, 1, 64, 0.125)   # N > 256 unsupported
+        k.attn_sinkhorn_fwd(qkv, 1, 300, 1, 64, 0.125)   # Sinkhorn attention holds the whole head on chip: N <= 256
 
 
 def test_cast_transpose_batched_matches_single(dev):

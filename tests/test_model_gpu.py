@@ -146,6 +146,13 @@ VT_CASES = {
     # the full vit_s_16 of the bench (configs[1]: D 384, 6 heads, M 1536, 12 layers; N = 384 runs the 384 x 128 NT tile), batch 2
     "vit_s_16_full": (dict(image_size=224, patch_size=16, num_layers=12, num_heads=6, hidden_dim=384, mlp_dim=1536, num_classes=1000), 2,
                       1.0e-2, 8.8e-3, 2.2e-2),     # measured 5.3e-3, 4.4e-3 (emulating vs fp32 oracle: 5.2e-3), 1.13e-2 (layer 0 ln_1.weight); loss 7.1418 vs 7.1446
+    # vit_h_14 geometry (vit.py:512-519: patch 14, 16 heads x 80, D 1280, M 5120, 257 tokens): 1 of its 32 layers.  Head dim 80 and
+    # N > 256 both go through the streaming attention kernels (csrc/nrv_attn_gen.hip)
+    "vit_h_14_l1": (dict(image_size=224, patch_size=14, num_layers=1, num_heads=16, hidden_dim=1280, mlp_dim=5120, num_classes=9), 2,
+                    1.2e-2, 1.2e-2, 2.0e-2),       # measured 3.2e-3, 2.7e-3 (emulating vs fp32 oracle 4.8e-3), 7.4e-3 (conv_proj.weight)
+    # ViT-B/16 at 384 px (577 tokens: what interpolate_embeddings, vit.py:522-603, produces checkpoints for): 1 layer
+    "vit_b_16_384px_l1": (dict(image_size=384, patch_size=16, num_layers=1, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=9), 1,
+                          1.2e-2, 1.2e-2, 2.0e-2),  # measured 5.4e-3, 1.7e-3 (emulating vs fp32 oracle 6.7e-3), 7.5e-3 (conv_proj.weight)
     # the full vit_l_16 of the bench (24 layers, 1000 classes), batch 1
     "vit_l_16_full": (dict(image_size=224, patch_size=16, num_layers=24, num_heads=16, hidden_dim=1024, mlp_dim=4096, num_classes=1000), 1,
                       9.7e-3, 7.2e-3, 2.0e-2),     # measured 4.9e-3, 3.6e-3 (emulating vs fp32 oracle: 4.4e-3), 1.04e-2 (layer 0 ln_1.weight); loss 5.9773 vs 5.9798
@@ -409,6 +416,57 @@ def test_simplevit_other_input_size_than_constructed(dev):
         logits = model(x.to(dev))
         emu = O.simple_vit_forward(sd, x, patch_size=16, heads=2, emulate_bf16=True)
         assert relmax(logits, emu) < LOGIT_TOL_EMULATED, (hw, relmax(logits, emu))
+
+
+def test_checkpoint_at_higher_resolution_through_interpolate_embeddings(dev):
+    """What interpolate_embeddings exists for (vit.py:522-603): a checkpoint trained at 224 px (197 tokens) is resized to
+    384 px (577 tokens) and runs there -- the attention goes through the streaming kernels (N > 256).  Checked against the
+    oracle run on the SAME interpolated state dict."""
+    from collections import OrderedDict
+    from noise_robust_vit_amd.vit import VisionTransformer, interpolate_embeddings
+    from oracle import vit_oracle as V
+    cfg = dict(patch_size=16, num_layers=1, num_heads=4, hidden_dim=256, mlp_dim=512, num_classes=7)
+    torch.manual_seed(0)
+    src = VisionTransformer(image_size=224, **cfg)
+    torch.nn.init.normal_(src.heads.head.weight, std=0.05)
+    sd224 = OrderedDict((k, v.detach().clone()) for k, v in src.state_dict().items())
+    sd384 = interpolate_embeddings(384, 16, sd224)
+    assert sd384["encoder.pos_embedding"].shape == (1, 577, 256)
+    model = VisionTransformer(image_size=384, **cfg)
+    model.load_state_dict(sd384)
+    model = model.to(dev).eval()
+    x = torch.randn(2, 3, 384, 384, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        logits = model(x.to(dev))
+    sd = {k: v.detach().clone() for k, v in sd384.items()}
+    ref = V.vit_forward(sd, x, patch_size=16, num_heads=4)
+    emu = V.vit_forward(sd, x, patch_size=16, num_heads=4, emulate_bf16=True)
+    e_ref, e_emu = relmax(logits, ref), relmax(logits, emu)
+    print(f"224 -> 384 px checkpoint (577 tokens): logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}")
+    assert e_ref < 1.2e-2 and e_emu < 1.2e-2
+
+
+def test_simplevit_with_other_head_dim(dev):
+    """SimpleViT(dim_head=32) (simple_vit.py:101-114: inner = heads * dim_head != dim): the streaming attention kernels take
+    head dims 32 / 80 / 96 / 128 beside the single-pass kernels' 64."""
+    from noise_robust_vit_amd import SimpleViT
+    from oracle import simple_vit_oracle as O
+    for dim_head, heads in ((32, 3), (96, 2), (128, 1)):
+        torch.manual_seed(0)
+        model = SimpleViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=heads, mlp_dim=256, dim_head=dim_head)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model = model.to(dev)
+        x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+        y = torch.randint(0, 10, (3,), generator=torch.Generator().manual_seed(4))
+        logits = model(x.to(dev))
+        torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.1).backward()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.simple_vit_forward(leaves, x, patch_size=16, heads=heads, dim_head=dim_head)
+        O.cross_entropy_ls(ref, y).backward()
+        emu = O.simple_vit_forward(sd, x, patch_size=16, heads=heads, dim_head=dim_head, emulate_bf16=True)
+        assert relmax(logits, ref) < LOGIT_TOL_FP32REF, (dim_head, relmax(logits, ref))
+        assert relmax(logits, emu) < LOGIT_TOL_EMULATED, (dim_head, relmax(logits, emu))
+        check_grads(model, {k: v.grad for k, v in leaves.items()}, tol=GRAD_RELL2_TOL)
 
 
 def test_lucid_vit_rejects_other_input_size(dev):

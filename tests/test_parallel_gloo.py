@@ -209,3 +209,60 @@ def test_forced_collectives_world_one_equal_plain_run():
     ref_out, _ = _reference()
     for k in ref_out:
         assert torch.equal(torch.from_numpy(out[k]), ref_out[k]), k
+
+
+def _worker_bf16(rank, world, port, q):
+    """grad_dtype="bf16": each rank's bucket is rounded to bf16, reduced, and converted back; tail_mib caps the last bucket."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from noise_robust_vit_amd.parallel import GradReducer
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 16, generator=g); Y = torch.randint(0, 5, (8,), generator=g)
+    net = Net()
+    _ = net(X[:2])                                       # a forward BEFORE the reducer exists (warm-up / sanity pass)
+    red = GradReducer(net, world, bucket_mib=64.0, grad_dtype="bf16", tail_mib=0.0005)
+    tr = Trainer(net, TrainConfig(lr=1e-2, grad_max_norm=5.0), red)
+    per = 8 // world
+    xs, ys = X[rank * per:(rank + 1) * per], Y[rank * per:(rank + 1) * per]
+    tr.forward_backward(xs, ys)
+    grads = {k: p.grad.detach().clone().numpy() for k, p in net.named_parameters()}
+    if rank == 0:
+        q.put((grads, red.bucket_bytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_cost_and_tail_bucket():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, buckets = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, ref_grads = _reference_grads_only()
+    worst = 0.0
+    for k, ref in ref_grads.items():
+        got = torch.from_numpy(grads[k])
+        # the stated numerical cost: every addend rounded to 8 significant bits before the mean, the mean rounded once more
+        assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max() + 1e-7, k
+        worst = max(worst, ((got - ref).norm() / ref.norm()).item())
+    assert worst < 6e-3, worst                           # measured: ~2e-3 relative L2 (bf16 epsilon 3.9e-3)
+    # tail cap 0.0005 MiB = 131 floats: the last bucket is cut down to the last parameter of the backward order alone
+    # (Net.w, 24 x 32 floats -- larger than the cap by itself, and a bucket never splits a parameter)
+    assert len(buckets) == 2 and buckets[-1] == 4 * 24 * 32
+
+
+def _reference_grads_only():
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 16, generator=g); Y = torch.randint(0, 5, (8,), generator=g)
+    net = Net()
+    tr = Trainer(net, TrainConfig(lr=1e-2, grad_max_norm=5.0), None)
+    tr.forward_backward(X, Y)
+    return None, {k: p.grad.detach().clone() for k, p in net.named_parameters()}
