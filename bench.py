@@ -248,6 +248,12 @@ def main():
 
     for _ in range(args.warmup):
         trainer.step(x, y)
+    if args.graph:
+        if use_pg:
+            raise SystemExit("--graph: single process only (collectives are not captured)")
+        trainer.capture(x, y)
+        for _ in range(2):
+            trainer.step(x, y)
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -286,6 +292,7 @@ def main():
                                    f"rccl all_reduce(AVG) of {args.grad_dtype} gradients per {args.bucket_mib:g} MiB bucket (last bucket <= "
                                    f"{args.tail_mib:g} MiB; buckets {[round(b / 2**20, 1) for b in reducer.bucket_bytes()]} MiB); {pg_desc}"
                                    + (", forced at world 1" if world == 1 else ", overlapped with backward")),
+                   "launch": "one HIP graph per step (Trainer.capture)" if args.graph else "eager (one C-ABI call per kernel)",
                    "residual_stream": "fp32", "gemm_operands": "bf16", "accumulate": "fp32",
                    "timing": f"{args.warmup} warm-up + {args.steps} timed steps, barrier + synchronize on both sides; "
                              "ms_per_step_median = median of per-step HIP-event spans on the compute stream"},

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 8
+#define NRV_ABI_VERSION 9
 
 /* dtype codes */
 #define NRV_F32 0
@@ -162,6 +162,20 @@ int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16, const flo
                           void* dqkv_bf16, int B, int N, int H, int dh, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Stand-alone SinkhornAttention(scores)  (the reference's exported module, utils.py:1025-1037, applied to a MATERIALISED
+ * score tensor; the training path uses the fused nrv_attn_sinkhorn_* above and never materialises scores):
+ *   P = softmax(S, -1); iters x { P /= rowsum(P); P /= colsum(P) }; P /= rowsum(P)        (reference default iters = 3)
+ *   scores / out / dout / dscores: fp32 [G, R, C] contiguous (G = product of the leading dimensions), R, C <= 4096.
+ *   Saved for the backward: lse fp32 [G, R] (row log-sum-exp of S), avec fp32 [G, iters + 1, R] and bvec fp32 [G, iters, C]:
+ *   the cumulative row / column scalings after every step (P = diag(avec[iters]) softmax(S) diag(bvec[iters - 1])).
+ *   dscores also serves as the backward's working matrix (it may not alias dout).
+ * ---------------------------------------------------------------------------------------- */
+int nrv_sinkhorn_fwd(const float* scores, float* out, float* lse, float* avec, float* bvec,
+                     int64_t G, int R, int C, int iters, void* stream);
+int nrv_sinkhorn_bwd(const float* scores, const float* dout, const float* lse, const float* avec, const float* bvec,
+                     float* dscores, int64_t G, int R, int C, int iters, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Patch unfold (replaces einops Rearrange 'b c (h p1) (w p2) -> b h w (p1 p2 c)' simple_vit.py:126-129,
  * and the im2col implied by Conv2d(k=s=p) vit.py:237-242,323).
  *   img [B,C,H,W] (img_dtype fp32|bf16) -> patches bf16 [B*(H/p)*(W/p), FP], FP = C*p*p rounded up to a multiple of 8
@@ -211,12 +225,15 @@ int nrv_scatter_rows_f32(const float* dout, const int64_t* index, float* dsrc,
  *                   -- torch.optim.AdamW (amsgrad = False, maximize = False) arithmetic, step >= 1.
  *   Hyper-parameters are doubles (1 - beta and the bias corrections are formed in double, then rounded, as torch does).
  *   p, grad, m, v: fp32 [n], 16-byte aligned; gnorm_sq: DEVICE pointer to one float (no host round trip).
+ *   step_scalars (optional, DEVICE pointer to 3 floats): { 1 - lr * weight_decay, lr / (1 - beta1^step),
+ *   1 / sqrt(1 - beta2^step) } read by the kernel INSTEAD of the values derived from lr / weight_decay / step -- a captured
+ *   HIP graph replays one launch with every step's learning rate and bias corrections (the caller refreshes the 3 floats).
  * ---------------------------------------------------------------------------------------- */
 size_t nrv_sumsq_workspace(int64_t n);
 int nrv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
 int nrv_adamw_f32(float* p, const float* grad, float* m, float* v, int64_t n,
                   double lr, double beta1, double beta2, double eps, double weight_decay, int step,
-                  const float* gnorm_sq, float max_norm, void* stream);
+                  const float* gnorm_sq, float max_norm, const float* step_scalars, void* stream);
 
 /* Hardware-assumption probes used by tests/test_kernels_gpu.py (test_probe_*) (MFMA lane maps, transposed LDS read,
  * LDS-DMA layout and out-of-range zero fill).  out: fp32 scratch written by a single wave. */

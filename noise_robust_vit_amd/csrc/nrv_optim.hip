@@ -71,7 +71,12 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
 __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            long long n4, long long n, const float* __restrict__ gnorm_sq,
-                                                           const AdamWArgs a) {
+                                                           const float* __restrict__ step_scalars, AdamWArgs a) {
+    if (step_scalars != nullptr) {          // the step-dependent scalars from device memory (a captured HIP graph replays this
+        a.decay = step_scalars[0];          // launch with other learning rates and bias corrections: optim.FusedAdamW)
+        a.step_size = step_scalars[1];
+        a.inv_bc2_sqrt = step_scalars[2];
+    }
     float coef = 1.0f;
     if (gnorm_sq != nullptr && a.max_norm > 0.f) {
         // clip_grad_norm_: coef = clamp(max_norm / (total_norm + 1e-6), max = 1)
@@ -124,7 +129,7 @@ extern "C" int nrv_sumsq_f32(const float* x, int64_t n, float* out, void* worksp
 
 extern "C" int nrv_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n,
                              double lr, double beta1, double beta2, double eps, double weight_decay, int step,
-                             const float* gnorm_sq, float max_norm, void* stream) {
+                             const float* gnorm_sq, float max_norm, const float* step_scalars, void* stream) {
     if (!p || !g || !m || !v) return NRV_ERR_NULL;
     if (n <= 0 || step < 1) return NRV_ERR_SHAPE;
     if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return NRV_ERR_SHAPE;
@@ -146,7 +151,7 @@ extern "C" int nrv_adamw_f32(float* p, const float* g, float* m, float* v, int64
     long long blocks = (n4 + OPT_THREADS - 1) / OPT_THREADS;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, p, g, m, v, n4, (long long)n, gnorm_sq, a);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, p, g, m, v, n4, (long long)n, gnorm_sq, step_scalars, a);
     NRV_CHECK_LAUNCH();
     return 0;
 }

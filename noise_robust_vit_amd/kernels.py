@@ -401,8 +401,10 @@ def sumsq(x: Tensor, out: Tensor, ws: Tensor) -> None:
 
 
 def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
-               weight_decay: float, step: int, gnorm_sq: Optional[Tensor], max_norm: float) -> None:
-    """In-place clip + AdamW on flat fp32 buffers (include/nrv.h: nrv_adamw_f32)."""
+               weight_decay: float, step: int, gnorm_sq: Optional[Tensor], max_norm: float,
+               step_scalars: Optional[Tensor] = None) -> None:
+    """In-place clip + AdamW on flat fp32 buffers (include/nrv.h: nrv_adamw_f32).  `step_scalars`: device tensor of 3 floats
+    that replaces the step-dependent scalars (graph replay)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _f32(t, n)
     if not (p.numel() == g.numel() == m.numel() == v.numel()):
@@ -411,8 +413,41 @@ def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: flo
     _run("optimizer", 0.0, p.numel() * 28,
          lambda: lib.nrv_adamw_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                                   _ptr(gnorm_sq), float(max_norm), _stream()),
+                                   _ptr(gnorm_sq), float(max_norm), _ptr(step_scalars), _stream()),
          "nrv_adamw_f32")
+
+
+def sinkhorn_fwd(scores: Tensor, iters: int = 3):
+    """SinkhornAttention(scores) on a materialised fp32 score tensor [..., R, C] (utils.py:1025-1037) -> (P, lse, avec, bvec)."""
+    _f32(scores, "scores")
+    if scores.dim() < 2:
+        raise NrvError("sinkhorn_fwd: scores must have at least two dimensions")
+    s = scores.contiguous()
+    R, C = s.shape[-2], s.shape[-1]
+    G = s.numel() // (R * C)
+    out = torch.empty_like(s)
+    lse = torch.empty(G, R, dtype=torch.float32, device=s.device)
+    avec = torch.empty(G, iters + 1, R, dtype=torch.float32, device=s.device)
+    bvec = torch.empty(G, max(iters, 1), C, dtype=torch.float32, device=s.device)
+    lib = _lib.load()
+    _run("sinkhorn_norm_fwd", 0.0, s.numel() * 4 * (2 * iters + 3),
+         lambda: lib.nrv_sinkhorn_fwd(s.data_ptr(), out.data_ptr(), lse.data_ptr(), avec.data_ptr(), bvec.data_ptr(),
+                                      G, R, C, int(iters), _stream()), "nrv_sinkhorn_fwd")
+    return out, lse, avec, bvec
+
+
+def sinkhorn_bwd(scores: Tensor, dout: Tensor, lse: Tensor, avec: Tensor, bvec: Tensor, iters: int = 3) -> Tensor:
+    _f32(scores, "scores"); _f32(dout, "dout")
+    s = scores.contiguous()
+    d = dout.contiguous()
+    R, C = s.shape[-2], s.shape[-1]
+    G = s.numel() // (R * C)
+    ds = torch.empty_like(s)
+    lib = _lib.load()
+    _run("sinkhorn_norm_bwd", 0.0, s.numel() * 4 * (4 * iters + 6),
+         lambda: lib.nrv_sinkhorn_bwd(s.data_ptr(), d.data_ptr(), lse.data_ptr(), avec.data_ptr(), bvec.data_ptr(), ds.data_ptr(),
+                                      G, R, C, int(iters), _stream()), "nrv_sinkhorn_bwd")
+    return ds
 
 
 def cast_transpose_batched(jobs) -> None:

@@ -12,6 +12,7 @@ torch.optim.AdamW's (pinned against it in tests/test_optim_gpu.py); the layout i
 """
 from __future__ import annotations
 
+import math
 from typing import Dict
 
 import torch
@@ -42,6 +43,22 @@ class FusedAdamW:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = torch.empty(max(K.sumsq_workspace(self.grad.numel()) // 4, 4), dtype=torch.float32, device=dev)
         self.step_count = 0
+        # step-dependent scalars in device memory (graph replay): { 1 - lr wd, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) }
+        self._dyn = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def stage_step_scalars(self, lr: float = None) -> None:
+        """Advance the step count and put this step's learning rate / bias corrections into device memory: what
+        `step(..., from_device=True)` -- the launch a captured HIP graph replays -- reads instead of host arguments.
+        Same double-precision arithmetic as the C ABI's host side (csrc/nrv_optim.hip)."""
+        self.step_count += 1
+        lr = self.lr if lr is None else float(lr)
+        b1, b2 = self.betas
+        t = self.step_count
+        # a fresh pinned staging tensor per step: the host runs several replays ahead of the device, and the caching host
+        # allocator does not hand a pinned block out again before the asynchronous copy that reads it has run
+        host = torch.tensor([1.0 - lr * self.weight_decay, lr / (1.0 - math.pow(b1, t)), 1.0 / math.sqrt(1.0 - math.pow(b2, t)), 0.0],
+                            dtype=torch.float32).pin_memory()
+        self._dyn.copy_(host, non_blocking=True)
 
     def _check_layout(self) -> None:
         for p in self.reducer.parameters():
@@ -49,11 +66,14 @@ class FusedAdamW:
                 raise NrvError("a parameter was re-allocated after FusedAdamW was built (e.g. model.to(...)): "
                                "build the optimizer after the model is on its device")
 
-    def step(self, max_norm: float = 0.0, lr: float = None) -> None:
-        """One AdamW step on every parameter; max_norm > 0 clips the global gradient norm first (clip_grad_norm_)."""
-        if self.step_count == 0:
+    def step(self, max_norm: float = 0.0, lr: float = None, from_device: bool = False) -> None:
+        """One AdamW step on every parameter; max_norm > 0 clips the global gradient norm first (clip_grad_norm_).
+        `from_device`: the step count, learning rate and bias corrections come from `stage_step_scalars()` (device memory)
+        instead of this call's arguments -- the form train.Trainer captures into a HIP graph."""
+        if self.step_count == 0 or (from_device and self.step_count == 1):
             self._check_layout()
-        self.step_count += 1
+        if not from_device:
+            self.step_count += 1
         if max_norm and max_norm > 0:
             K.sumsq(self.grad, self.gnorm_sq, self._ws)
         # parameters without a gradient this step are skipped like torch.optim.AdamW skips `p.grad is None` (no weight decay,
@@ -64,7 +84,8 @@ class FusedAdamW:
         for lo, hi in self._active_ranges():
             K.adamw_flat(self.param[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                          self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                         self.step_count, self.gnorm_sq if max_norm and max_norm > 0 else None, float(max_norm or 0.0))
+                         max(self.step_count, 1), self.gnorm_sq if max_norm and max_norm > 0 else None, float(max_norm or 0.0),
+                         step_scalars=self._dyn if from_device else None)
         # the parameters changed through raw pointers: their version counters did not move, so the bf16 weight images
         # (encoder.WeightCache, keyed on the version) are re-staged explicitly -- all of them in one batched launch
         from .encoder import WEIGHTS

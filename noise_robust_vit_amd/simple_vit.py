@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from .encoder import AttnHalfFn, BlockMeta, EncoderStackFn, MlpHalfFn, PatchEmbedFn
-from ._lib import PATCH_P1P2C
+from ._lib import PATCH_P1P2C, NrvError
 
 
 def _pair(t):
@@ -37,17 +37,43 @@ def sincos_table_2d(h: int, w: int, dim: int, temperature: float = 10000.0, devi
     return torch.cat((ax.sin(), ax.cos(), ay.sin(), ay.cos()), dim=1).to(torch.float32).contiguous()
 
 
+class _SinkhornNormFn(torch.autograd.Function):
+    """softmax + Sinkhorn normalisations of a materialised score tensor through nrv_sinkhorn_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, scores, iters: int):
+        from . import kernels as K
+        if not scores.is_cuda:
+            raise NrvError("noise_robust_vit_amd runs on the MI355X (HIP) device only; there is no CPU fallback")
+        s32 = scores.detach().to(torch.float32).contiguous()
+        out, lse, avec, bvec = K.sinkhorn_fwd(s32, iters)
+        ctx.save_for_backward(s32, lse, avec, bvec)
+        ctx.iters, ctx.dtype = iters, scores.dtype
+        return out.to(scores.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import kernels as K
+        s32, lse, avec, bvec = ctx.saved_tensors
+        ds = K.sinkhorn_bwd(s32, dout.to(torch.float32).contiguous(), lse, avec, bvec, ctx.iters)
+        return ds.to(ctx.dtype), None
+
+
 class SinkhornAttention(nn.Module):
-    """Marker for `robust=True`: softmax followed by 3 x (row, column) normalisations and a final row
-    normalisation (utils.py:1025-1037).  The arithmetic is fused into the attention kernel."""
+    """`robust=True`: softmax followed by `sinkhorn_iterations` x (row, column) normalisations and a final row normalisation
+    (utils.py:1025-1037).  Inside the attention modules the arithmetic is fused into the HIP attention kernel and this object
+    is only the marker the reference's `Attention.attend` slot holds; called directly on a score tensor [..., R, C] it runs
+    the stand-alone kernels of csrc/nrv_sinknorm.hip (forward and backward)."""
 
     def __init__(self, dim: int = -1, sinkhorn_iterations: int = 3) -> None:
         super().__init__()
         self.dim = dim
         self.sinkhorn_iterations = sinkhorn_iterations
 
-    def forward(self, scores):          # only reached if someone calls the marker directly
-        raise RuntimeError("SinkhornAttention is fused into the HIP attention kernel; call the Attention module")
+    def forward(self, scores):
+        if self.dim not in (-1, scores.dim() - 1):
+            raise NotImplementedError("SinkhornAttention: the softmax dimension must be the last one (the reference's default)")
+        return _SinkhornNormFn.apply(scores, int(self.sinkhorn_iterations))
 
 
 class PatchUnfold(nn.Module):

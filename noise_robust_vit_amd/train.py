@@ -86,6 +86,7 @@ class Trainer:
             self.opt = torch.optim.AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay, eps=1e-8, betas=(0.9, 0.999))
         self.fused = on_gpu
         self.step_idx = 0
+        self._graph = None
         self.rng = np.random.default_rng(cfg.seed)
 
     def loss_fn(self, logits: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
@@ -137,9 +138,70 @@ class Trainer:
         self.step_idx += 1
 
     def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        if self._graph is not None:
+            return self._replay(x, y)
         loss = self.forward_backward(x, y)
         self.optimizer_step()
         return loss
+
+    # ---- whole-step HIP graph -------------------------------------------------------------------
+    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2) -> None:
+        """Capture forward + loss + backward + clip + AdamW + weight re-staging (one training step, ~370 - 830 kernel launches)
+        into ONE HIP graph; afterwards `step()` copies the batch into the captured input buffers, refreshes three device
+        scalars (learning rate, bias corrections) and replays the graph.  What this removes is the host: 13 ms of ctypes /
+        autograd enqueue per ViT-S step and the idle gap at the step boundary; the kernels are the same launches.
+        Training state is untouched by the capture (the warm-up steps it needs are rolled back), so a captured trainer
+        continues exactly where the eager one stood.  Single process only (no collectives are captured), no CutMix (its
+        box is drawn on the host every step)."""
+        if not self.fused:
+            raise RuntimeError("Trainer.capture needs the MI355X path (FusedAdamW)")
+        if self.cfg.cutmix_prob > 0.0:
+            raise RuntimeError("Trainer.capture: CutMix draws its box on the host every step and cannot be replayed")
+        if self.reducer is not None and (self.reducer.world > 1 or self.reducer.force):
+            raise RuntimeError("Trainer.capture: collectives are not captured; use the eager step with a process group")
+        opt = self.opt
+        saved = (opt.param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count, self.step_idx)
+        rng_state = torch.cuda.get_rng_state(x.device)
+        self._gx, self._gy = x.clone(), y.clone()
+
+        def body():
+            loss = self.forward_backward(self._gx, self._gy)
+            opt.step(max_norm=self.cfg.grad_max_norm or 0.0, from_device=True)
+            return loss
+
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):       # allocator pools, weight-cache job tables, lazy kernel attributes
+                opt.stage_step_scalars(self.cfg.lr)
+                body()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        opt.stage_step_scalars(self.cfg.lr)
+        with torch.cuda.graph(graph):
+            self._gloss = body()
+        # roll the state back: nothing above was a training step
+        with torch.no_grad():
+            opt.param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
+        opt.step_count, self.step_idx = saved[3], saved[4]
+        torch.cuda.set_rng_state(rng_state, x.device)
+        from .encoder import WEIGHTS
+        WEIGHTS.refresh_all()
+        self._graph = graph
+
+    def _replay(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        c = self.cfg
+        if x.data_ptr() != self._gx.data_ptr():
+            self._gx.copy_(x, non_blocking=True)
+        if y.data_ptr() != self._gy.data_ptr():
+            self._gy.copy_(y, non_blocking=True)
+        lr = warmup_cosine_lr(self.step_idx, c.lr, c.warmup_steps, c.cosine_steps) if (c.warmup_steps or c.cosine_steps) else c.lr
+        self.opt.stage_step_scalars(lr)
+        self._graph.replay()
+        self.step_idx += 1
+        return self._gloss
 
     @torch.no_grad()
     def eval_step(self, x: torch.Tensor, y: torch.Tensor, process_group=None) -> torch.Tensor:

@@ -564,3 +564,39 @@ def test_attention_probs_export(dev, B, N, H):
     ps = ps * a[..., :, None] * b[..., None, :]
     _, pref = sinkhorn_ref(qkv, B, N, H, dh, scale)
     assert (ps - pref).abs().max().item() < 1e-4 * max(1.0, pref.abs().max().item())
+
+
+# ------------------------------------------------------------------ stand-alone SinkhornAttention(scores)
+def _sinkhorn_ref(S, iters=3):
+    Q = torch.softmax(S, dim=-1)                        # utils.py:1031-1037
+    for _ in range(iters):
+        Q = Q / Q.sum(dim=-1, keepdim=True)
+        Q = Q / Q.sum(dim=-2, keepdim=True)
+    return Q / Q.sum(dim=-1, keepdim=True)
+
+
+def test_sinkhorn_module_on_scores_matches_reference_fixture(dev, golden_dir):
+    """`SinkhornAttention()(scores)` (the module the reference exports, utils.py:1025-1037) against the vector produced by the
+    reference implementation itself (tests/golden/sinkhorn_unit.npz, gen_golden.py)."""
+    import numpy as np
+    from noise_robust_vit_amd import SinkhornAttention
+    g = np.load(f"{golden_dir}/sinkhorn_unit.npz")
+    out = SinkhornAttention()(torch.from_numpy(g["scores"]).to(dev))
+    assert (out.cpu() - torch.from_numpy(g["out"])).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("shape,iters", [((2, 3, 7, 7), 3), ((4, 197, 197), 3), ((1, 2, 300, 300), 3), ((3, 50, 81), 3),
+                                         ((2, 64, 64), 0), ((2, 33, 65), 5), ((1, 1, 1), 3)])
+def test_sinkhorn_module_forward_backward(dev, shape, iters):
+    from noise_robust_vit_amd import SinkhornAttention
+    S = rnd(shape, dev, 170, 1.5, torch.float32).requires_grad_(True)
+    mod = SinkhornAttention(sinkhorn_iterations=iters)
+    P = mod(S)
+    Sr = S.detach().double().requires_grad_(True)
+    Pr = _sinkhorn_ref(Sr, iters)
+    assert (P.double() - Pr).abs().max().item() < 1e-5 * Pr.abs().max().item() + 1e-7
+    W = rnd(shape, dev, 171, 1.0, torch.float32)
+    (P * W).sum().backward()
+    (Pr * W.double()).sum().backward()
+    rel = ((S.grad.double() - Sr.grad).norm() / Sr.grad.norm().clamp_min(1e-30)).item()
+    assert rel < 2e-4, rel
