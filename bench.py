@@ -315,7 +315,7 @@ def main():
             gnt = summ["gemm_nt"]
             ach = gnt["flops"] / (gnt["ms"] * 1e-3) / 1e12
             traffic, tsrc = pmc_traffic(args.arch, batch, "gemm_nt")
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (MFMA bf16 NT GEMM, all epilogues)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt8_kernel / gemm_nt_kernel (MFMA bf16 NT GEMM, phased K loop, all epilogues)",
                                "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                                "launches_per_step": gnt["launches"] // 2,

@@ -1,8 +1,10 @@
 // LayerNorm forward/backward and column reductions for gfx950 -- HBM-bound kernels.
 //
-// One wave (64 lanes) owns one token row at a time; a lane holds 4-element chunks lane, lane+64, ...
-// of the row in registers (16-byte loads for fp32 rows, 8-byte for bf16), so a row is read exactly
-// once; mean / variance / the two backward dot products are wave shuffles.  gamma/beta gradients
+// LPR lanes own one token row at a time -- a whole wave (LPR = 64) for rows of more than 512 elements, HALF a wave (LPR = 32,
+// two rows per wave) below: at D = 384 (ViT-S) a 64-lane row leaves half of the second chunk's lanes idle and moved 4.3 / 4.6
+// TB/s where D = 768 moves 5.2 / 6.1.  A lane holds the 4-element chunks l, l + LPR, ... of its row in registers (16-byte
+// loads for fp32 rows, 8-byte for bf16), so a row is read exactly once; mean / variance / the two backward dot products are
+// shuffles inside the row's lane group.  gamma/beta gradients
 // and bias gradients are deterministic two-pass column reductions (per-workgroup partial rows, then
 // a small finalize kernel) -- no float atomics, bitwise reproducible.
 //
@@ -32,18 +34,26 @@ __device__ __forceinline__ void store4_bf16(bf16_t* base, long long idx, f32x4_t
     *reinterpret_cast<u32x2_t*>(base + idx) = pk;
 }
 __device__ __forceinline__ float sum4(f32x4_t v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {           // over the LPR lanes that share a row
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
-template <bool X_F32, int MAXJ>
+template <bool X_F32, int MAXJ, int LPR>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             long long rows, int dim, float eps) {
+    constexpr int RPW = 64 / LPR;                                   // rows per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
     const float inv_dim = 1.0f / (float)dim;
     f32x4_t g4[MAXJ], b4[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
-        const int c = (lane + 64 * j) * 4;
+        const int c = (l + LPR * j) * 4;
         if (c < dim) {
             g4[j] = *reinterpret_cast<const f32x4_t*>(gamma + c);
             b4[j] = *reinterpret_cast<const f32x4_t*>(beta + c);
@@ -52,37 +62,39 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restri
             b4[j] = g4[j];
         }
     }
-    for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long long)gridDim.x * LN_WAVES) {
+    for (long long row0 = ((long long)blockIdx.x * LN_WAVES + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * LN_WAVES * RPW) {
+        const long long row = row0 + sub;
+        const bool ok = row < rows;                                 // the second row of the last pair may not exist
         f32x4_t v[MAXJ];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            if (c < dim) {
+            const int c = (l + LPR * j) * 4;
+            if (ok && c < dim) {
                 v[j] = load4<X_F32>(x, row * dim + c);
                 s += sum4(v[j]);
             } else {
                 v[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
         }
-        const float mu = wave_sum(s) * inv_dim;
+        const float mu = group_sum<LPR>(s) * inv_dim;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int c = (lane + 64 * j) * 4;
+            const int c = (l + LPR * j) * 4;
             if (c < dim) {
                 const f32x4_t d = v[j] - mu;
                 q += sum4(d * d);
             }
         }
-        const float var = wave_sum(q) * inv_dim;
+        const float var = group_sum<LPR>(q) * inv_dim;
         const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            if (c < dim) store4_bf16(y, row * dim + c, (v[j] - mu) * rs * g4[j] + b4[j]);
+            const int c = (l + LPR * j) * 4;
+            if (ok && c < dim) store4_bf16(y, row * dim + c, (v[j] - mu) * rs * g4[j] + b4[j]);
         }
-        if (lane == 0) {
+        if (ok && l == 0) {
             mean[row] = mu;
             rstd[row] = rs;
         }
@@ -90,31 +102,35 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restri
 }
 
 // DRES: 0 = none, 1 = fp32, 2 = bf16
-template <bool X_F32, int DRES, int MAXJ>
+template <bool X_F32, int DRES, int MAXJ, int LPR>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const void* __restrict__ dres,
                                                             float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16,
                                                             float* __restrict__ partial, long long rows, int dim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
     const float inv_dim = 1.0f / (float)dim;
     f32x4_t g4[MAXJ], adg[MAXJ], adb[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
-        const int c = (lane + 64 * j) * 4;
+        const int c = (l + LPR * j) * 4;
         g4[j] = (c < dim) ? *reinterpret_cast<const f32x4_t*>(gamma + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         adg[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         adb[j] = adg[j];
     }
-    for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long long)gridDim.x * LN_WAVES) {
-        const float mu = mean[row], rs = rstd[row];
+    for (long long row0 = ((long long)blockIdx.x * LN_WAVES + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * LN_WAVES * RPW) {
+        const long long row = row0 + sub;
+        const bool ok = row < rows;
+        const float mu = ok ? mean[row] : 0.f, rs = ok ? rstd[row] : 0.f;
         f32x4_t xh[MAXJ], g[MAXJ];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            if (c < dim) {
+            const int c = (l + LPR * j) * 4;
+            if (ok && c < dim) {
                 const f32x4_t d = load4<false>(dy, row * dim + c);
                 xh[j] = (load4<X_F32>(x, row * dim + c) - mu) * rs;
                 g[j] = d * g4[j];
@@ -127,12 +143,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
                 g[j] = xh[j];
             }
         }
-        c1 = wave_sum(c1) * inv_dim;
-        c2 = wave_sum(c2) * inv_dim;
+        c1 = group_sum<LPR>(c1) * inv_dim;
+        c2 = group_sum<LPR>(c2) * inv_dim;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            if (c < dim) {
+            const int c = (l + LPR * j) * 4;
+            if (ok && c < dim) {
                 f32x4_t d = (g[j] - c2 - xh[j] * c1) * rs;
                 if (DRES == 1) d += load4<true>(dres, row * dim + c);
                 if (DRES == 2) d += load4<false>(dres, row * dim + c);
@@ -141,20 +157,21 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
             }
         }
     }
-    // cross-wave reduction of the column partials through LDS: [LN_WAVES][dim] floats, dgamma then dbeta
+    // reduction of the column partials over the row groups of the workgroup through LDS: [LN_WAVES * RPW][dim] floats,
+    // dgamma then dbeta (fixed order)
     float* red = reinterpret_cast<float*>(smem);
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            if (c < dim) *reinterpret_cast<f32x4_t*>(red + wave * dim + c) = pass == 0 ? adg[j] : adb[j];
+            const int c = (l + LPR * j) * 4;
+            if (c < dim) *reinterpret_cast<f32x4_t*>(red + (wave * RPW + sub) * dim + c) = pass == 0 ? adg[j] : adb[j];
         }
         __syncthreads();
         for (int c = threadIdx.x * 4; c < dim; c += LN_THREADS * 4) {
             f32x4_t s = *reinterpret_cast<const f32x4_t*>(red + c);
 #pragma unroll
-            for (int w = 1; w < LN_WAVES; ++w) s += *reinterpret_cast<const f32x4_t*>(red + w * dim + c);
+            for (int w = 1; w < LN_WAVES * RPW; ++w) s += *reinterpret_cast<const f32x4_t*>(red + w * dim + c);
             *reinterpret_cast<f32x4_t*>(partial + ((long long)blockIdx.x * 2 + pass) * dim + c) = s;
         }
     }
@@ -215,37 +232,50 @@ __global__ __launch_bounds__(RR_COLS * RR_LANES) void reduce_rows_kernel(const f
     }
 }
 
-int ln_maxj(int dim) {
-    const int chunks = (dim / 4 + 63) / 64;
-    int m = 1;
-    while (m < chunks) m <<= 1;
-    return m;
+int ln_lpr(int dim) { return dim <= 512 ? 32 : 64; }             // lanes per row: half a wave for short rows
+int ln_maxj(int dim) {                                             // 4-element chunks per lane, rounded up to a dispatched count
+    const int lpr = ln_lpr(dim);
+    const int chunks = (dim / 4 + lpr - 1) / lpr;
+    static const int steps[8] = {1, 2, 3, 4, 5, 6, 8, 16};
+    for (int k = 0; k < 8; ++k)
+        if (chunks <= steps[k]) return steps[k];
+    return 16;
 }
 
 template <bool X_F32, int MAXJ>
 void launch_ln_fwd(const void* x, const float* g, const float* b, bf16_t* y, float* mean, float* rstd,
                    long long rows, int dim, float eps, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((ln_fwd_kernel<X_F32, MAXJ>), dim3(grid), dim3(LN_THREADS), 0, s, x, g, b, y, mean, rstd, rows, dim, eps);
+    if (ln_lpr(dim) == 32)
+        hipLaunchKernelGGL((ln_fwd_kernel<X_F32, (MAXJ > 4 ? 4 : MAXJ), 32>), dim3(grid), dim3(LN_THREADS), 0, s, x, g, b, y, mean, rstd, rows, dim, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<X_F32, MAXJ, 64>), dim3(grid), dim3(LN_THREADS), 0, s, x, g, b, y, mean, rstd, rows, dim, eps);
 }
 
 template <bool X_F32, int DRES, int MAXJ>
 void launch_ln_bwd(const bf16_t* dy, const void* x, const float* g, const float* mean, const float* rstd, const void* dres,
                    float* dxf, bf16_t* dxb, float* partial, long long rows, int dim, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((ln_bwd_kernel<X_F32, DRES, MAXJ>), dim3(grid), dim3(LN_THREADS), (size_t)LN_WAVES * dim * 4, s,
-                       dy, x, g, mean, rstd, dres, dxf, dxb, partial, rows, dim);
+    if (ln_lpr(dim) == 32)
+        hipLaunchKernelGGL((ln_bwd_kernel<X_F32, DRES, (MAXJ > 4 ? 4 : MAXJ), 32>), dim3(grid), dim3(LN_THREADS), (size_t)LN_WAVES * 2 * dim * 4, s,
+                           dy, x, g, mean, rstd, dres, dxf, dxb, partial, rows, dim);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<X_F32, DRES, MAXJ, 64>), dim3(grid), dim3(LN_THREADS), (size_t)LN_WAVES * dim * 4, s,
+                           dy, x, g, mean, rstd, dres, dxf, dxb, partial, rows, dim);
 }
 
 #define NRV_DISPATCH_MAXJ(MJ, CALL)            \
     switch (MJ) {                              \
         case 1: { constexpr int J = 1; CALL; } break;   \
         case 2: { constexpr int J = 2; CALL; } break;   \
+        case 3: { constexpr int J = 3; CALL; } break;   \
         case 4: { constexpr int J = 4; CALL; } break;   \
+        case 5: { constexpr int J = 5; CALL; } break;   \
+        case 6: { constexpr int J = 6; CALL; } break;   \
         case 8: { constexpr int J = 8; CALL; } break;   \
         default: { constexpr int J = 16; CALL; } break; \
     }
 
-int ln_bwd_grid(int64_t rows) {
-    int64_t g = nrv_cdiv(rows, LN_WAVES);
+int ln_bwd_grid(int64_t rows, int dim) {
+    int64_t g = nrv_cdiv(rows, LN_WAVES * (64 / ln_lpr(dim)));
     if (g > LN_BWD_BLOCKS) g = LN_BWD_BLOCKS;
     if (g < 1) g = 1;
     return (int)g;
@@ -260,7 +290,7 @@ extern "C" int nrv_layernorm_fwd(const void* x, int x_dtype, const float* gamma,
     if (rows <= 0 || dim <= 0 || (dim & 7) || dim > 4096) return NRV_ERR_SHAPE;
     if (x_dtype != NRV_F32 && x_dtype != NRV_BF16) return NRV_ERR_DTYPE;
     if (!nrv_aligned16(x) || !nrv_aligned16(gamma) || !nrv_aligned16(beta) || !nrv_aligned16(y_bf16)) return NRV_ERR_ALIGN;
-    int64_t g = nrv_cdiv(rows, LN_WAVES);
+    int64_t g = nrv_cdiv(rows, LN_WAVES * (64 / ln_lpr(dim)));
     if (g > LN_FWD_BLOCKS) g = LN_FWD_BLOCKS;
     const int grid = (int)g;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -277,7 +307,7 @@ extern "C" int nrv_layernorm_fwd(const void* x, int x_dtype, const float* gamma,
 
 extern "C" size_t nrv_layernorm_bwd_workspace(int64_t rows, int dim) {
     if (rows <= 0 || dim <= 0) return 0;
-    return (size_t)ln_bwd_grid(rows) * 2 * (size_t)dim * 4;
+    return (size_t)ln_bwd_grid(rows, dim) * 2 * (size_t)dim * 4;
 }
 
 extern "C" int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const float* gamma,
@@ -295,7 +325,7 @@ extern "C" int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype
     if (!nrv_aligned16(dy_bf16) || !nrv_aligned16(x) || !nrv_aligned16(gamma) || !nrv_aligned16(workspace) ||
         (dres && !nrv_aligned16(dres)) || (dx_f32 && !nrv_aligned16(dx_f32)) || (dx_bf16 && !nrv_aligned16(dx_bf16)))
         return NRV_ERR_ALIGN;
-    const int grid = ln_bwd_grid(rows);
+    const int grid = ln_bwd_grid(rows, dim);
     if (workspace_bytes < (size_t)grid * 2 * (size_t)dim * 4) return NRV_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t* dy = static_cast<const bf16_t*>(dy_bf16);

@@ -60,7 +60,7 @@ def test_probe_lds_dma_linear_and_oob_zero(dev):
 
 
 # ------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("rows,dim", [(32, 192), (1000, 768), (777, 384), (64, 1024), (5, 64), (130, 4096)])
+@pytest.mark.parametrize("rows,dim", [(32, 192), (1000, 768), (777, 384), (64, 1024), (5, 64), (130, 4096), (333, 512), (257, 1280), (1, 384)])
 @pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
 def test_layernorm_fwd_bwd(dev, rows, dim, xdt):
     k = _k()

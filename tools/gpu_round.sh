@@ -3,7 +3,7 @@
 # the bench lines of the other BASELINE configs.  Usage (through gpurun): bash tools/gpu_round.sh <tag> [quick|notests|others]
 # (quick: tests + headline evidence only; others: only the other configs)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

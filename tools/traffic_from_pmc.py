@@ -14,7 +14,8 @@ def load(path, counter):
             continue
         key = (r["Dispatch_Id"], r["Kernel_Name"])
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-        cls = ("gemm_nt" if "gemm_nt_kernel" in name else "gemm_tn" if "gemm_tn_kernel" in name else
+        cls = ("gemm_nt" if ("gemm_nt_kernel" in name or "gemm_nt8_kernel" in name) else
+               "gemm_tn" if ("gemm_tn_kernel" in name or "gemm_tn8_kernel" in name) else
                "splitk_reduce" if "splitk_reduce" in name else "attn_fwd" if "attn_fwd" in name else
                "attn_bwd" if "attn_bwd" in name else "ln_fwd" if "ln_fwd" in name else "ln_bwd" if "ln_bwd" in name else None)
         if cls is None:
