@@ -1306,7 +1306,7 @@ int device_cus() {
     return n;
 }
 
-int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
+int nt_tile_choice(int64_t M, int64_t N, int64_t K, bool allow_384n) {
     (void)K;
     // One workgroup per CU: the kernel takes ceil(tiles / CUs) rounds of one tile time each, and a tile's time grows with
     // its height (MFMA work ~ rows; operand traffic ~ rows + 256).  Pick the height with the smallest rounds x cost;
@@ -1326,7 +1326,7 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
     // Cost 300 per tile from the ViT-S sweep (profiles/r02_nt_tile_sweep_128_column_tiles.txt: 52.5 vs 58.9 us on
     // [50432 x 384 x 1152], 67.0 vs 75.8 on [50432 x 384 x 1536]; both grids take 2 rounds)
     const int64_t tn128 = nrv_cdiv(N, 128);
-    if (tn128 * 128 < tn * 256) {
+    if (allow_384n && tn128 * 128 < tn * 256) {
         const double c = (double)nrv_cdiv(nrv_cdiv(M, 384) * tn128, cus) * 300.0;
         if (c < best_cost * 0.999) { best = 1384; best_cost = c; }
     }
@@ -1335,7 +1335,10 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K) {
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
-    const int tc = NRV_TUNE_NT_TILE(nt_tile_choice(p.e.M, p.e.N, p.K));      // identity in the product (csrc/nrv_dev.hpp)
+    // the 384 x 128 tile keeps the two-stage loop: with the fp32 residual epilogue and a long K the phased 256 x 256 loop wins
+    // although it computes the padding columns (profiles/r03_nt_tile_sweep.txt: [50432 x 384 x 1536] 94.8 vs 111.1 us)
+    const bool allow_384n = !(EPI == NRV_EPI_BIAS_RESIDUAL && p.K >= 1024);
+    const int tc = NRV_TUNE_NT_TILE(nt_tile_choice(p.e.M, p.e.N, p.K, allow_384n));      // identity in the product (csrc/nrv_dev.hpp)
     if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
         return launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);    // one launch per step: 256-row tiles only
     if (tc == 1384) return launch_nt_cfg<Cfg384n, EPI, OUT_F32, AUX_F32, false>(p, s);

@@ -34,6 +34,17 @@ extern "C" int NRV_DEV_CAT(nrv_dev_read_stamps_, NRV_DEV_TU)(unsigned long long*
     return (int)hipMemcpy(host_out, nrv_dev_host_buf, count * 8, hipMemcpyDeviceToHost);
 }
 
+#ifdef NRV_DEV_NO_STAMPS        // tile-sweep builds: only the tile override below, the kernels stay the product's
+#define NRV_STAMP_VARS(n)
+#define NRV_STAMP(i)
+#define NRV_STAMP_FLUSH_WG(n, tid)
+#define NRV_WACC_VARS
+#define NRV_WACC_MARK()
+#define NRV_WACC(i)
+#define NRV_WACC_FLUSH(nwaves, wave, lane)
+#define NRV_STAMP_SEQ_VARS(tid)
+#define NRV_STAMP_SEQ()
+#else
 #define NRV_STAMP_VARS(n) unsigned long long nrv_t_[n] = {}
 #define NRV_STAMP(i) do { nrv_t_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
 #define NRV_STAMP_FLUSH_WG(n, tid)                                                                                      \
@@ -67,7 +78,8 @@ extern "C" int NRV_DEV_CAT(nrv_dev_read_stamps_, NRV_DEV_TU)(unsigned long long*
         if (nrv_sq_on_) nrv_dev_buf[(unsigned long long)blockIdx.x * 16 + nrv_sq_i_] = __builtin_amdgcn_s_memtime();    \
         ++nrv_sq_i_;                                                                                                    \
     } while (0)
-// tile sweep builds: python tools/build_dev.py t256 --instrument -DNRV_FORCE_NT_TILE=256   (128 / 192 / 256 / 320 / 1384)
+#endif
+// tile sweep builds: python tools/build_dev.py t256 --instrument -DNRV_DEV_NO_STAMPS -DNRV_FORCE_NT_TILE=256   (128 / 192 / 256 / 320 / 1384)
 #ifdef NRV_FORCE_NT_TILE
 #define NRV_TUNE_NT_TILE(choice) (NRV_FORCE_NT_TILE)
 #else

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""NT GEMM tile-height sweep: the forced-tile developer builds (tools/build_dev.py tNNN --instrument -DNRV_FORCE_NT_TILE=NNN) timed in
+"""NT GEMM tile-height sweep: the forced-tile developer builds (tools/build_dev.py tNNN --instrument -DNRV_DEV_NO_STAMPS -DNRV_FORCE_NT_TILE=NNN) timed in
 interleaved rounds on the shapes of every BASELINE config; prints the fastest height per shape next to what the product's
 cost model (`nt_tile_choice`) picks.  GPU only; dev tool."""
 import os, sys, statistics
