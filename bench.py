@@ -293,6 +293,8 @@ def main():
                                    f"{args.tail_mib:g} MiB; buckets {[round(b / 2**20, 1) for b in reducer.bucket_bytes()]} MiB); {pg_desc}"
                                    + (", forced at world 1" if world == 1 else ", overlapped with backward")),
                    "launch": "one HIP graph per step (Trainer.capture)" if args.graph else "eager (one C-ABI call per kernel)",
+                   "streams": "weight-gradient GEMMs on a second HIP stream where the dX grid leaves >= 15 % of its CU-rounds idle "
+                              "(encoder.WGRAD_STREAM = auto; not on ViT-B/16 at batch 256); the per-launch timing leg runs on one stream",
                    "residual_stream": "fp32", "gemm_operands": "bf16", "accumulate": "fp32",
                    "timing": f"{args.warmup} warm-up + {args.steps} timed steps, barrier + synchronize on both sides; "
                              "ms_per_step_median = median of per-step HIP-event spans on the compute stream"},

@@ -18,6 +18,7 @@ Nothing here computes with torch ops: torch supplies memory, streams and the aut
 """
 from __future__ import annotations
 
+import functools
 import weakref
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
@@ -151,8 +152,66 @@ def sink_params(params) -> list:
     return out
 
 
+# Weight gradients on a second HIP stream.  dW = dy^T x only feeds the optimizer, so it can run beside the dX chain (the NT GEMM
+# of the same layer reads the same dy) and take the CUs that chain leaves idle: with one 512-thread workgroup per CU a grid
+# of 316 or 396 tiles (ViT-L, ViT-S, the MAE encoder) occupies 62 - 77 % of its CU-rounds.  Measured on the whole step
+# (profiles/r03_wgrad_stream_ab.txt): ViT-S -2.5 %, ViT-L -2.1 %, MAE -2.6 %; ViT-B/16 at batch 256 (474 tiles, 93 %) +-0.1 %,
+# where the chip is already power-limited -- so the stream is used only when the dX grid fills its rounds poorly ("auto").
+WGRAD_STREAM = "auto"            # "auto" | True | False
+WGRAD_MIN_IDLE = 0.15
+_WGRAD_SIDE = {}
+_WGRAD_KEEP: list = []
+
+
+def _wgrad_side(device) -> "torch.cuda.Stream":
+    s = _WGRAD_SIDE.get(device.index)
+    if s is None:
+        s = _WGRAD_SIDE[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+@functools.lru_cache(maxsize=None)
+def _dx_grid_idle(rows: int, cols: int, cus: int) -> float:
+    """Share of CU-rounds the [rows x cols] dX GEMM leaves empty under the best of the NT kernel's tile heights (256-column tiles)."""
+    best = 1.0
+    for h in (256, 320, 192, 128):
+        tiles = -(-rows // h) * -(-cols // 256)
+        best = min(best, 1.0 - tiles / (-(-tiles // cus) * cus))
+    return best
+
+
+def _wgrad_on_side(dy16: Tensor, x16: Tensor) -> bool:
+    if K._PROF is not None:                  # per-launch timing (bench.py's roofline leg): one stream, every launch timed alone
+        return False
+    if WGRAD_STREAM == "auto":
+        # judged on the layer's narrow side (the residual width: every second GEMM of the dX chain has that many columns);
+        # deciding per GEMM instead was measured 0.5 - 1 % slower on ViT-S / ViT-L than moving the whole layer's weight gradients
+        cus = torch.cuda.get_device_properties(x16.device).multi_processor_count
+        return _dx_grid_idle(x16.shape[0], min(x16.shape[1], dy16.shape[1]), cus) >= WGRAD_MIN_IDLE
+    return bool(WGRAD_STREAM)
+
+
+def wgrad_join() -> None:
+    """The current stream waits for every weight gradient issued so far; their operands may be freed afterwards."""
+    if _WGRAD_KEEP:
+        dev = _WGRAD_KEEP[0][0].device
+        torch.cuda.current_stream(dev).wait_stream(_wgrad_side(dev))
+        _WGRAD_KEEP.clear()
+
+
 def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
-    """Weight and bias gradient of y = x W^T + b in ONE kernel: dW = dy^T x on the MFMA, db = colsum(dy) fused."""
+    """Weight and bias gradient of y = x W^T + b in ONE kernel: dW = dy^T x on the MFMA, db = colsum(dy) fused.
+    With a gradient sink (results go to persistent buffers nobody reads before `wgrad_join`) the launch may go to the side stream."""
+    if meta.sink is not None and _wgrad_on_side(dy16, x16):
+        side = _wgrad_side(dy16.device)
+        side.wait_stream(torch.cuda.current_stream(dy16.device))
+        _WGRAD_KEEP.append((dy16, x16))          # alive until the join: the allocator must not hand them out while the side stream reads
+        with torch.cuda.stream(side):
+            return _dw_db_run(meta, dy16, x16, w, b)
+    return _dw_db_run(meta, dy16, x16, w, b)
+
+
+def _dw_db_run(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
     parts = getattr(w, "_nrv_parts", None)
     if parts is not None and meta.sink is not None:
         # w stacks the rows of several parameters ([to_q; to_kv]): one TN GEMM per parameter on the matching column block of
@@ -334,6 +393,7 @@ def _mask_sink_grads(meta: BlockMeta, grads: List[Optional[Tensor]]) -> List[Opt
     """With a sink attached the kernels already wrote into the sink's buffers: hand autograd nothing."""
     if meta.sink is None:
         return grads
+    wgrad_join()
     return [None for _ in grads]
 
 
@@ -371,6 +431,7 @@ class EncoderStackFn(torch.autograd.Function):
             d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True)
             d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0)
             grads[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = ga + gm
+            wgrad_join()
             saved[i] = None                                  # free this block's activations early
             if meta.sink is not None:
                 meta.sink.layer_done(i, sink_params(p))

@@ -108,3 +108,36 @@ def test_graph_replay_of_the_whole_step_is_bit_equal_to_the_eager_step(dev):
     assert replayed == eager, (replayed, eager)
     for k, v in m2.state_dict().items():
         assert torch.equal(v, p1[k]), k
+
+
+def test_weight_gradients_on_the_side_stream_follow_the_one_stream_trajectory(dev):
+    """encoder.WGRAD_STREAM: the TN GEMMs of a layer run on a second HIP stream, joined before the layer's gradients are
+    declared final.  Same kernels, same operands: 5 unsynchronised training steps must give bit-identical losses, parameters
+    and gradient buffers whether the side stream is used (True; 'auto' picks it for this small grid too) or not."""
+    from noise_robust_vit_amd import SimpleViT, encoder
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+
+    g = torch.Generator(device=dev).manual_seed(11)
+    xs = [torch.randn(16, 3, 64, 64, generator=g, device=dev).to(torch.bfloat16) for _ in range(5)]
+    ys = [torch.randint(0, 10, (16,), generator=g, device=dev) for _ in range(5)]
+    results = {}
+    prev = encoder.WGRAD_STREAM
+    try:
+        for mode in (False, True, "auto"):
+            encoder.WGRAD_STREAM = mode
+            torch.manual_seed(0)
+            encoder.WEIGHTS.clear()
+            m = SimpleViT(image_size=64, patch_size=16, num_classes=10, dim=192, depth=3, heads=3, mlp_dim=384).to(dev).train()
+            t = Trainer(m, TrainConfig(lr=1e-3, weight_decay=0.05, grad_max_norm=1.0))
+            losses = [t.step(x, y) for x, y in zip(xs, ys)]
+            torch.cuda.synchronize()
+            assert not encoder._WGRAD_KEEP, "operands of side-stream GEMMs still held after the step"
+            results[mode] = ([float(l) for l in losses], t.reducer.flat.clone(), {k: v.clone() for k, v in m.state_dict().items()})
+    finally:
+        encoder.WGRAD_STREAM = prev
+    base = results[False]
+    for mode in (True, "auto"):
+        assert results[mode][0] == base[0], mode
+        assert torch.equal(results[mode][1], base[1]), mode
+        for k, v in base[2].items():
+            assert torch.equal(results[mode][2][k], v), (mode, k)
