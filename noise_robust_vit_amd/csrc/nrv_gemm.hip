@@ -75,6 +75,7 @@ struct GemmNTParams {
     int K;
     int tiles_n;
     int gn;                       // column-group width of the tile order (0 = plain row-major sweep)
+    int ntiles;                   // gemm_nt8_kernel (persistent): tiles of the whole output, >= gridDim.x
     EpiParams e;
 };
 
@@ -115,14 +116,30 @@ __device__ __forceinline__ int remap_row(int m, int group, int group_stride, int
 typedef __attribute__((ext_vector_type(4))) unsigned rawx4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned rawx2_t;
 
+// Buffer stores of the epilogue (row offset = scalar soffset).  The hardware reads the store data AFTER issue.  For a store of
+// more than 8 bytes hipcc keeps the wait states the ISA asks for before a VALU overwrite of the data registers only when
+// soffset is not a register; with a register soffset it emits none.  On gfx950 with the vector-memory path busy (eight waves
+// storing, LDS-DMA of the next tile in flight) an immediately following VALU write of a data register did reach the store:
+// element 1 of an fp32 pass came out as the next pass's row index, intermittently (tools/nt_diag.py; first seen with the
+// persistent kernel, latent in every build before it).  The data registers stay live across two wait states behind the store.
+__device__ __forceinline__ void store_b128_row(rawx4_t v, __amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, 0);
+    asm volatile("s_nop 1" :: "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_b64_row(rawx2_t v, __amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, 0);
+    asm volatile("s_nop 1" :: "v"(v) : "memory");
+}
+
 template <int EPI, bool OUT_F32, bool AUX_F32, int MI>
-__device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], char* smem, const EpiParams& e,
+__device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /* the wave's 4-KiB LDS patch */, const EpiParams& e,
                                              int row_base /* global row of the wave's block (wave-uniform) */,
                                              int col_base /* global col of the wave's block (wave-uniform) */,
-                                             int lane, int wave_u) {
+                                             int lane) {
     const int rows_left = e.M - row_base, cols_left = e.N - col_base;
     if (rows_left <= 0 || cols_left <= 0) return;                       // uniform: the whole block is outside
-    float* stg = reinterpret_cast<float*>(smem + wave_u * EPI_PATCH_BYTES);
+    // patch: 16 rows of 64 floats, the 16-byte unit u of row r stored at unit u ^ r: conflict-free b128 writes (16 lanes =
+    // 16 rows of one column group) and reads (16 lanes = 16 / 2 x 8 units of one / two rows) without padding
     const int wc_row = lane & 15, wg = lane >> 4;       // write side: row within slab, column group
     constexpr int CW = OUT_F32 ? 4 : 8;                 // columns per lane on the read side: one 16-byte store
     constexpr int V = CW / 4;                           // float4 pieces per lane
@@ -140,16 +157,21 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], char* smem, 
     constexpr int HALF = MI > 8 ? (MI + 3) / 4 : (MI + 1) / 2;      // operand-prefetch depth, bounded by the register file
 
     // descriptors: base = the wave's block, records end with the last valid column of the last valid row
-    const int c_rs = (int)e.ldc * ES;
+    // row strides: opaque per call, so that inside a persistent tile loop the per-pass offsets r0 * stride are computed here (one
+    // s_mul each) instead of being hoisted out of the loop as 20 - 80 scalar registers that live, spilled, through the K loops
+    int c_rs = (int)e.ldc * ES;
+    asm volatile("" : "+s"(c_rs));
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(static_cast<char*>(e.C) + ((long long)row_base * e.ldc + col_base) * ES,
                                                 ((unsigned long long)(rows_here - 1) * e.ldc + cols_here) * ES);
     const unsigned c_vo = col_ok ? (unsigned)(rrow * c_rs + rcol * CW * ES) : NRV_OOB;
-    const int a_rs = HAS_AUX ? (int)e.ld_aux * AS : 0;
+    int a_rs = HAS_AUX ? (int)e.ld_aux * AS : 0;
+    asm volatile("" : "+s"(a_rs));
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(HAS_AUX ? static_cast<const char*>(e.aux) + ((long long)row_base * e.ld_aux + col_base) * AS : nullptr,
                                                 HAS_AUX ? ((unsigned long long)(rows_here - 1) * e.ld_aux + cols_here) * AS : 0ull);
     const unsigned a_vo = (HAS_AUX && col_ok) ? (unsigned)(rrow * a_rs + rcol * CW * AS) : NRV_OOB;
     const bool want_u = EPI == NRV_EPI_BIAS_GELU && e.aux_out != nullptr;
-    const int u_rs = want_u ? (int)e.ld_aux_out * 2 : 0;
+    int u_rs = want_u ? (int)e.ld_aux_out * 2 : 0;
+    asm volatile("" : "+s"(u_rs));
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(want_u ? static_cast<char*>(e.aux_out) + ((long long)row_base * e.ld_aux_out + col_base) * 2 : nullptr,
                                                 want_u ? ((unsigned long long)(rows_here - 1) * e.ld_aux_out + cols_here) * 2 : 0ull);
     const unsigned u_vo = (want_u && col_ok) ? (unsigned)(rrow * u_rs + rcol * CW * 2) : NRV_OOB;
@@ -199,13 +221,13 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], char* smem, 
             if (mi < MI) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
-                    *reinterpret_cast<f32x4_t*>(stg + wc_row * EPI_ROW_F32 + ni * 16 + wg * 4) = acc[mi][ni];
+                    *reinterpret_cast<f32x4_t*>(stg + wc_row * 64 + (((ni * 4 + wg) ^ wc_row) << 2)) = acc[mi][ni];
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int r = rrow + RPI * i;
                     f32x4_t val[V];
 #pragma unroll
-                    for (int v = 0; v < V; ++v) val[v] = *reinterpret_cast<const f32x4_t*>(stg + r * EPI_ROW_F32 + rcol * CW + 4 * v);
+                    for (int v = 0; v < V; ++v) val[v] = *reinterpret_cast<const f32x4_t*>(stg + r * 64 + (((rcol * V + v) ^ r) << 2));
                     const int r0 = mi * 16 + RPI * i;                    // first row of the pass within the block (uniform)
                     if (r0 < rows_here) {                                // scalar branch; later rows of the pass: range check
                         unsigned pk[2 * V], pku[2 * V];
@@ -233,7 +255,7 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], char* smem, 
                                 else x *= a;
                             }
                             if (OUT_F32) {
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rawx4_t, x), rc, c_vo + 16 * v, r0 * c_rs, 0);
+                                store_b128_row(__builtin_bit_cast(rawx4_t, x), rc, c_vo + 16 * v, r0 * c_rs);
                             } else {
                                 pk[2 * v] = pack_bf16x2(x[0], x[1]);
                                 pk[2 * v + 1] = pack_bf16x2(x[2], x[3]);
@@ -241,15 +263,15 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], char* smem, 
                         }
                         if (!OUT_F32) {      // V == 2: one 16-byte store of 8 bf16
                             const rawx4_t o = {pk[0], pk[1], pk[2 * V - 2], pk[2 * V - 1]};
-                            __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_vo, r0 * c_rs, 0);
+                            store_b128_row(o, rc, c_vo, r0 * c_rs);
                         }
                         if (EPI == NRV_EPI_BIAS_GELU && want_u) {
                             if (V == 2) {
                                 const rawx4_t o = {pku[0], pku[1], pku[2 * V - 2], pku[2 * V - 1]};
-                                __builtin_amdgcn_raw_buffer_store_b128(o, ru, u_vo, r0 * u_rs, 0);
+                                store_b128_row(o, ru, u_vo, r0 * u_rs);
                             } else {
                                 const rawx2_t o = {pku[0], pku[1]};
-                                __builtin_amdgcn_raw_buffer_store_b64(o, ru, u_vo, r0 * u_rs, 0);
+                                store_b64_row(o, ru, u_vo, r0 * u_rs);
                             }
                         }
                     }
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
     __syncthreads();     // every wave is done with the tile buffers: reuse them as epilogue patches
     NRV_STAMP(2);
     if (REMAP) epilogue_remap<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
-    else epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane, wave);
+    else epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, reinterpret_cast<float*>(smem + wave * EPI_PATCH_BYTES), p.e, m0 + wr * (C::MI * 16), n0 + wc * (C::NI * 16), lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no-ops in the product: the hooks below are empty
     NRV_STAMP(3);
     NRV_STAMP_FLUSH_WG(4, tid);
@@ -551,6 +573,42 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// vector-memory instructions of one full-block epilogue_lin per wave (stores + epilogue-operand loads; the bias loads are not
+// counted: they are the oldest and a LOWER bound is what the counted waits behind an epilogue need)
+template <int EPI, bool OUT_F32, bool AUX_F32, int MI>
+constexpr int epilogue_vm_ops() {
+    constexpr int CW = OUT_F32 ? 4 : 8, NIT = 16 / (64 / (64 / CW));
+    constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
+    constexpr int AS = (EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32) ? 4 : 2, AW = CW * AS / 4;
+    return MI * NIT * (1 + (EPI == NRV_EPI_BIAS_GELU ? 1 : 0) + (HAS_AUX ? (AW <= 4 ? 1 : AW / 4) : 0));
+}
+
+template <typename C>
+constexpr int nt8_stage_bytes() { return (C::TBM + C::TBN) * 128; }
+template <typename C>
+constexpr bool nt8_patches_behind() { return 2 * nt8_stage_bytes<C>() + 8 * 4096 <= 160 * 1024; }
+template <typename C>
+constexpr int nt8_lds_bytes() { return 2 * nt8_stage_bytes<C>() + (nt8_patches_behind<C>() ? 8 : 4) * 4096; }
+
+struct Nt8Tile {                     // what the staging ops and the epilogue of one output tile need (scalar registers)
+    __amdgpu_buffer_rsrc_t ra0, ra1, rb0, rb1;
+    unsigned ka1, kb1;
+    int m0, n0;
+};
+
+// PERSISTENT over tiles: workgroup b computes the tiles b, b + gridDim.x, ... (one workgroup per CU).  The half-tile op
+// pipeline runs THROUGH the tile boundary: the six phases of a tile's last 1.5 K-steps, which have no op of their own tile
+// left to issue, issue ops 0 .. 5 of the NEXT tile (its K-step 0 whole, A0 and B0 of its K-step 1), so a tile's epilogue runs
+// with the next tile's first operands landing behind it and the next K loop starts without a prologue, a workgroup
+// turnaround or a cold start (measured on the round-3 one-tile-per-workgroup kernel: 1.7 - 2.7 us prologue + ~3 us between a
+// workgroup's last store and its successor's first stamp, per 29 - 36 us tile at K = 768).
+//   * LDS during an epilogue: both stage buffers are taken except the A1 / B1 halves of the stage the tile's last K-step
+//     used.  The wave-private epilogue patches of waves 4-7 live in that A1 half (its next writer, op A1 of the next tile's
+//     K-step 1, is issued behind a barrier every wave reaches after its epilogue), those of waves 0-3 in 16 KiB behind the
+//     stage buffers.  The wave groups are re-aligned in front of the epilogue and staggered again behind it.
+//   * vmcnt is in issue order for loads and stores alike, so the waits of the next tile's K-step 0 count the epilogue's own
+//     stores as "younger ops that may stay in flight" (E of them for a full block; an edge block, whose epilogue skips
+//     passes, falls back to the plain count and waits for its stores): the K loop does not wait for the store drain.
 template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTParams p) {
     static_assert(C::WM == 2 && C::WN == 4 && C::NI == 4 && C::MI % 2 == 0, "2 x 4 waves, 64-column wave blocks");
@@ -560,45 +618,62 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     constexpr int STG = 2 * AH + 2 * BH;
     constexpr int PA = AH / 1024, PB = BH / 1024;                   // 1-KiB DMA pieces (8 rows) per half
     static_assert(PB % 8 == 0 && PA % 4 == 0, "pieces divide over the waves");
+    constexpr bool PATCH_BEHIND = nt8_patches_behind<C>();          // all eight patches behind the stage buffers, or waves 4-7 in an A half
+    static_assert(PATCH_BEHIND || AH >= 4 * 4096, "four epilogue patches fit an A half");
     // pieces of an A half per wave: PA / 8, the remainder (MI = 10: 4 pieces) goes to waves 0-3 in half 0 and to waves 4-7
     // in half 1, so that every wave issues the same number per K-step and per window of four consecutive ops
     constexpr int NA = (PA + 7) / 8, NB = PB / 8;
     constexpr bool A_UNEVEN = (PA % 8) != 0;
     constexpr int W4 = (A_UNEVEN ? 2 * NA - 1 : 2 * NA) + 2 * NB;   // DMA instructions of four consecutive ops (one per kind)
+    constexpr int E_OPS = epilogue_vm_ops<EPI, OUT_F32, AUX_F32, C::MI>();
+    constexpr int W4E = W4 + E_OPS > 63 ? 63 : W4 + E_OPS;          // vmcnt is a 6-bit field: 63 outstanding = at most the 63 youngest
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    NRV_STAMP_VARS(4);
+    NRV_TILE_STAMP_VARS(wave);       // hooks: empty in the product (csrc/nrv_dev.hpp)
     NRV_WACC_VARS;
-    NRV_STAMP(0);
+    NRV_TILE_STAMP();                // [0] start
 
-    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    if (p.gn > 0 && p.tiles_n > p.gn) {
-        const int tiles_m = gridDim.x / p.tiles_n;
-        const int gsize = tiles_m * p.gn;
-        const int grp = id / gsize, within = id - grp * gsize;
-        const int gw = (grp + 1) * p.gn <= p.tiles_n ? p.gn : p.tiles_n - grp * p.gn;
-        tm = within / gw;
-        tn = grp * p.gn + (within - tm * gw);
-    } else {
-        tm = id / p.tiles_n;
-        tn = id - tm * p.tiles_n;
-    }
-    const int m0 = tm * C::TBM, n0 = tn * C::TBN;
     const int M = p.e.M, N = p.e.N;
     const int nk = p.K / BK;                                        // host: K % 64 == 0, nk >= 3
+    const unsigned ntiles = (unsigned)p.ntiles;
 
-    // One descriptor per half: based at the half's first row / column, records = the valid rows behind it, so that rows
-    // >= M - m0 / >= N - n0 read as zero and the per-lane offsets are the same for both halves.  The K position is the scalar
-    // soffset, which the range check subtracts from the records: a half without a valid row (records 0) keeps soffset 0.
-    const int ar1 = M - m0 - 8 * C::MI, br1 = N - n0 - 32;
-    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(p.A + (long long)m0 * p.lda, (unsigned long long)(M - m0) * p.lda * 2ull);
-    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(p.A + (long long)(m0 + (ar1 > 0 ? 8 * C::MI : 0)) * p.lda, (unsigned long long)(ar1 > 0 ? ar1 : 0) * p.lda * 2ull);
-    const __amdgpu_buffer_rsrc_t rb0 = make_rsrc(p.B + (long long)n0 * p.ldb, (unsigned long long)(N - n0) * p.ldb * 2ull);
-    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(p.B + (long long)(n0 + (br1 > 0 ? 32 : 0)) * p.ldb, (unsigned long long)(br1 > 0 ? br1 : 0) * p.ldb * 2ull);
-    const unsigned ka1 = ar1 > 0 ? ~0u : 0u, kb1 = br1 > 0 ? ~0u : 0u;
+    // tile t of this workgroup's sequence.  One descriptor per half: based at the half's first row / column, records = the
+    // valid rows behind it, so that rows >= M - m0 / >= N - n0 read as zero and the per-lane offsets are the same for both
+    // halves.  The K position is the scalar soffset, which the range check subtracts from the records: a half without a
+    // valid row (records 0) keeps soffset 0.
+    auto make_tile = [&](unsigned t, bool valid) {                  // !valid: descriptors without records (their DMA writes zeros)
+        const unsigned id = xcd_remap(valid ? t : 0u, ntiles);
+        int tm, tn;
+        if (p.gn > 0 && p.tiles_n > p.gn) {
+            const int tiles_m = (int)ntiles / p.tiles_n;
+            const int gsize = tiles_m * p.gn;
+            const int grp = id / gsize, within = id - grp * gsize;
+            const int gw = (grp + 1) * p.gn <= p.tiles_n ? p.gn : p.tiles_n - grp * p.gn;
+            tm = within / gw;
+            tn = grp * p.gn + (within - tm * gw);
+        } else {
+            tm = id / p.tiles_n;
+            tn = id - tm * p.tiles_n;
+        }
+        // the divisions above run on the vector ALU (reciprocal); bring the results back explicitly so that everything
+        // derived from them (descriptors, masks) stays in scalar registers
+        tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
+        Nt8Tile d;
+        d.m0 = tm * C::TBM; d.n0 = tn * C::TBN;
+        const int ar0 = valid ? M - d.m0 : 0, br0 = valid ? N - d.n0 : 0;
+        const int ar1 = ar0 - 8 * C::MI, br1 = br0 - 32;
+        d.ra0 = make_rsrc(p.A + (long long)d.m0 * p.lda, (unsigned long long)ar0 * p.lda * 2ull);
+        d.ra1 = make_rsrc(p.A + (long long)(d.m0 + (ar1 > 0 ? 8 * C::MI : 0)) * p.lda, (unsigned long long)(ar1 > 0 ? ar1 : 0) * p.lda * 2ull);
+        d.rb0 = make_rsrc(p.B + (long long)d.n0 * p.ldb, (unsigned long long)br0 * p.ldb * 2ull);
+        d.rb1 = make_rsrc(p.B + (long long)(d.n0 + (br1 > 0 ? 32 : 0)) * p.ldb, (unsigned long long)(br1 > 0 ? br1 : 0) * p.ldb * 2ull);
+        // all-ones when the half has a valid row, by arithmetic: a select here is sunk through the cur / nxt hand-over as a
+        // loop-carried i1, which lives in a lane mask and drags the masks into vector registers
+        d.ka1 = (unsigned)__builtin_amdgcn_readfirstlane((-ar1) >> 31); d.kb1 = (unsigned)__builtin_amdgcn_readfirstlane((-br1) >> 31);
+        asm volatile("" : "+s"(d.ka1), "+s"(d.kb1));                // ... and the readfirstlane is not sunk behind the hand-over either
+        return d;
+    };
 
     // staging: piece q = 8 i + wave of a half covers its local rows 8 q .. 8 q + 7; local row r' of A half h is tile row
     // (16 MI) (r' / (8 MI)) + 8 MI h + r' % (8 MI), local row r' of B half h is tile column 64 (r' / 32) + 32 h + r' % 32
@@ -620,27 +695,36 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         st_b[i] = (unsigned)((long long)r * p.ldb * 2) + c * 16;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));    // LDS byte address of the tile buffers
-    // half-tile op `kind` (0: A0, 1: B0, 2: B1, 3: A1) of K-step t into stage buffer t & 1
-    auto stage = [&](auto kind_c, int t) {
+    // half-tile op `kind` (0: A0, 1: B0, 2: B1, 3: A1) of K-step t of tile d into stage buffer `par` (the parity of the
+    // workgroup's running K-step count: the stage buffers alternate through the tile boundaries)
+    auto stage_half = [&](auto kind_c, __amdgpu_buffer_rsrc_t r, unsigned mask, int t, int par) {
         constexpr int kind = decltype(kind_c)::value;
         constexpr bool isA = kind == 0 || kind == 3;
         constexpr int h = (kind == 2 || kind == 3) ? 1 : 0;
-        const unsigned base = lds0 + (t & 1) * STG + (isA ? h * AH : 2 * AH + h * BH);
-        unsigned so = (unsigned)(t * (BK * 2));
-        if constexpr (h == 1) so &= isA ? ka1 : kb1;
+        const unsigned base = lds0 + par * STG + (isA ? h * AH : 2 * AH + h * BH);
+        // uniform by construction; the readfirstlane costs nothing where hipcc sees that (the product) and keeps the operand a
+        // scalar register where it does not (instrumented builds: a thread-0 branch in the tile loop)
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * (BK * 2)) & mask));
         if constexpr (isA) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (A_UNEVEN && i == NA - 1) {
-                    if (wr == h) dma16s_at(h ? ra1 : ra0, base + ((NA - 1) * 8 + (wave & 3)) * 1024, st_a[i], so);
+                    if (wr == h) dma16s_at(r, base + ((NA - 1) * 8 + (wave & 3)) * 1024, st_a[i], so);
                 } else {
-                    dma16s_at(h ? ra1 : ra0, base + (i * 8 + wave) * 1024, st_a[i], so);
+                    dma16s_at(r, base + (i * 8 + wave) * 1024, st_a[i], so);
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) dma16s_at(h ? rb1 : rb0, base + (i * 8 + wave) * 1024, st_b[i], so);
+            for (int i = 0; i < NB; ++i) dma16s_at(r, base + (i * 8 + wave) * 1024, st_b[i], so);
         }
+    };
+    auto stage = [&](auto kind_c, const Nt8Tile& d, int t, int par) {
+        constexpr int kind = decltype(kind_c)::value;
+        if constexpr (kind == 0) stage_half(kind_c, d.ra0, ~0u, t, par);
+        else if constexpr (kind == 1) stage_half(kind_c, d.rb0, ~0u, t, par);
+        else if constexpr (kind == 2) stage_half(kind_c, d.rb1, d.kb1, t, par);
+        else stage_half(kind_c, d.ra1, d.ka1, t, par);
     };
 
     // fragment read addresses (LDS byte addresses of k-step 0 / 1 in the CURRENT stage buffer, half 0; half 1 = + AH / + BH
@@ -650,27 +734,43 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     unsigned ard[2], brd[2];
     ard[0] = lds0 + (wr * (8 * C::MI) + fr) * 128 + swz;      ard[1] = ard[0] ^ 64u;
     brd[0] = lds0 + 2 * AH + (wc * 32 + fr) * 128 + swz;      brd[1] = brd[0] ^ 64u;
-    int dstg = STG;
+    int dstg = STG;                                                 // > 0: the current stage buffer is buffer 0
     auto next_stage = [&]() {
         ard[0] += dstg; ard[1] += dstg; brd[0] += dstg; brd[1] += dstg;
         dstg = -dstg;
     };
 
-    f32x4_t acc[C::MI][4];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[C::MI][4];                                          // started by the MFMAs of every tile's K-step 0 (C = 0)
     bf16x8_t a[MH][2], b0[2][2], b1[2][2];
 
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
-    // one phase of K-step kt.  ST: issue this phase's half-tile op; WAIT: vmcnt to wait for before the barrier (-1: none)
-    auto phase = [&](auto P_c, auto ST_c, auto WAIT_c, int kt) {
+    // Late starts against lockstep.  Equal tiles keep the 256 CUs in step, so their epilogues coincide: 256 x 327 KB (gelu) ask
+    // for twice the HBM write rate while no CU computes, and nobody stores while all compute.  Workgroups that have one tile
+    // fewer than the busiest ones start late, spread over 3/4 of a tile time: free (their last tile still ends before the
+    // busiest workgroups' last), + 2.6 % on fc1 and + 4 % on dU of ViT-B/16.  Spreading the busiest workgroups too (30 / 60 % of
+    // a tile time) only added the delay on every shape, fp32-residual epilogues included (profiles/r03_nt8_late_start_spread.txt).
+    {
+        const unsigned rem = ntiles % gridDim.x;
+        if (ntiles > gridDim.x && rem != 0 && blockIdx.x >= rem) {
+            const unsigned tile_cycles = (unsigned)nk * (C::MI * 330u) + 6000u;
+            const unsigned span = tile_cycles - tile_cycles / 4;
+            const unsigned naps = (blockIdx.x - rem) * (span / 8128u) / (gridDim.x - rem);  // s_sleep 127 = 8128 cycles
+            for (unsigned i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    Nt8Tile cur = make_tile(blockIdx.x, true), nxt = cur;
+    int kb = 0;                                                     // parity of the K-steps this workgroup ran before the current tile
+
+    // one phase of K-step kt of the current tile.  OP: 1 this phase's half-tile op is of the current tile, 2 of the next tile
+    // (K-step index counted on behind the current tile's last).  Counted wait before the barrier: vmcnt WA if `alt` else WB
+    // (-1: none); `alt` is wave-uniform, and only the wait sits behind the scalar branch
+    auto phase = [&](auto P_c, auto OP_c, auto WA_c, auto WB_c, int kt, bool alt, auto FIRST_c) {
         constexpr int P = decltype(P_c)::value;
-        constexpr bool ST = decltype(ST_c)::value;
-        constexpr int WAIT = decltype(WAIT_c)::value;
+        constexpr bool FIRST = decltype(FIRST_c)::value;          // K-step 0 of a tile: the accumulators start from the constant 0
+        constexpr int OP = decltype(OP_c)::value;
+        constexpr int WA = decltype(WA_c)::value, WB = decltype(WB_c)::value;
         if constexpr (P == 0) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -691,15 +791,29 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
 #pragma unroll
                 for (int ml = 0; ml < MH; ++ml) a[ml][ks] = lds_read_b128_at(ard[ks] + AH + ml * 2048);
         }
-        if constexpr (ST) {
+        if constexpr (OP != 0) {
             // global phase g = 4 kt + P issues op g + 6: B1 / A1 of K-step kt + 1 in phases 0 / 1, A0 / B0 of kt + 2 in 2 / 3
-            if constexpr (P == 0) stage(I2{}, kt + 1);
-            else if constexpr (P == 1) stage(I3{}, kt + 1);
-            else if constexpr (P == 2) stage(I0{}, kt + 2);
-            else stage(I1{}, kt + 2);
+            const int kk = kt + (P < 2 ? 1 : 2);
+            const int par = (kb + kk) & 1;
+            using KIND = std::integral_constant<int, P == 0 ? 2 : P == 1 ? 3 : P == 2 ? 0 : 1>;
+            if constexpr (OP == 1) {
+                stage(KIND{}, cur, kk, par);
+            } else {                                              // the op pipeline runs on into the next tile: K-step kk - nk of `nxt`
+                const bool over = kk >= nk;
+                constexpr int kind = KIND::value;
+                const __amdgpu_buffer_rsrc_t r = kind == 0 ? (over ? nxt.ra0 : cur.ra0) : kind == 1 ? (over ? nxt.rb0 : cur.rb0)
+                                               : kind == 2 ? (over ? nxt.rb1 : cur.rb1) : (over ? nxt.ra1 : cur.ra1);
+                const unsigned mask = kind == 2 ? (over ? nxt.kb1 : cur.kb1) : kind == 3 ? (over ? nxt.ka1 : cur.ka1) : ~0u;
+                stage_half(KIND{}, r, mask, over ? kk - nk : kk, par);
+            }
         }
         NRV_WACC(4 * P + 0);                                      // per phase P: section 0: fragment-read and DMA issue
-        if constexpr (WAIT >= 0) wait_vm<WAIT>();
+        if constexpr (WA == WB) {
+            if constexpr (WA >= 0) wait_vm<WA>();
+        } else {
+            if (alt) { if constexpr (WA >= 0) wait_vm<WA>(); }
+            else { if constexpr (WB >= 0) wait_vm<WB>(); }
+        }
         NRV_WACC(4 * P + 1);                                      // section 1: counted vmcnt wait
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -714,55 +828,82 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
             for (int ml = 0; ml < MH; ++ml)
 #pragma unroll
                 for (int nl = 0; nl < 2; ++nl)
-                    acc[mh + ml][nh + nl] = mfma16((P == 1 || P == 2) ? b1[nl][ks] : b0[nl][ks], a[ml][ks], acc[mh + ml][nh + nl]);
+                    acc[mh + ml][nh + nl] = mfma16((P == 1 || P == 2) ? b1[nl][ks] : b0[nl][ks], a[ml][ks],
+                                                   (FIRST && ks == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[mh + ml][nh + nl]);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         NRV_WACC(4 * P + 3);                                      // section 3: MFMA section + closing barrier
     };
-    using T = std::true_type; using F = std::false_type;
+    using OPC = std::integral_constant<int, 1>; using OPX = std::integral_constant<int, 2>;
+    using T_ = std::true_type; using F_ = std::false_type;
     using WN_ = std::integral_constant<int, -1>;                    // no wait
     using WF = std::integral_constant<int, W4>;                     // steady state: four ops in flight
-    // tail counts (no further ops are issued after phase 1 of K-step nk - 2).  With an uneven A split the two wave groups
-    // have NA - 1 / NA instructions in their last A1 op: the smaller count is safe for both (and keeps the tail branch-free)
-    constexpr int nA1 = A_UNEVEN ? NA - 1 : NA;
-    using WT2 = std::integral_constant<int, NB + nA1>;
-    using WT1 = std::integral_constant<int, nA1>;
-    using W0 = std::integral_constant<int, 0>;
-
-    // prologue: ops 0 .. 5 (K-step 0 whole, A0 and B0 of K-step 1); A0, B0 of K-step 0 landed before the first barrier
-    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0); stage(I0{}, 1); stage(I1{}, 1);
+    using WE = std::integral_constant<int, W4E>;                    // ... and the previous tile's epilogue stores behind them
+    // prologue (first tile only): ops 0 .. 5 (K-step 0 whole, A0 and B0 of K-step 1); A0, B0 of K-step 0 landed before the first barrier
+    stage(I0{}, cur, 0, 0); stage(I1{}, cur, 0, 0); stage(I2{}, cur, 0, 0); stage(I3{}, cur, 0, 0); stage(I0{}, cur, 1, 1); stage(I1{}, cur, 1, 1);
     wait_vm<W4>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                      // stagger: waves 4-7 one barrier behind
-    NRV_STAMP(1);
     NRV_WACC_MARK();
 
-    int kt = 0;
-    for (; kt < nk - 2; ++kt) {
-        phase(I0{}, T{}, WF{}, kt);
-        phase(I1{}, T{}, WF{}, kt);
-        phase(I2{}, T{}, WN_{}, kt);
-        phase(I3{}, T{}, WF{}, kt);
+    bool count_stores = false;       // the previous epilogue of this wave issued exactly E_OPS counted instructions
+    for (unsigned t = blockIdx.x;;) {
+        NRV_TILE_STAMP();            // [1 + 4 i] tile i: first K-step ready
+        const unsigned tnext = t + gridDim.x;
+        const bool has_next = tnext < ntiles;                       // uniform
+        nxt = make_tile(tnext, has_next);
+        // K-step 0: behind an epilogue its three waits also leave that epilogue's stores in flight
+        phase(I0{}, OPC{}, WE{}, WF{}, 0, count_stores, T_{});
+        phase(I1{}, OPC{}, WE{}, WF{}, 0, count_stores, T_{});
+        phase(I2{}, OPC{}, WN_{}, WN_{}, 0, false, T_{});
+        phase(I3{}, OPC{}, WE{}, WF{}, 0, count_stores, T_{});
         next_stage();
+        // K-steps 1 .. nk - 3: every op belongs to the current tile
+        int kt = 1;
+        for (; kt < nk - 2; ++kt) {
+            phase(I0{}, OPC{}, WF{}, WF{}, kt, false, F_{});
+            phase(I1{}, OPC{}, WF{}, WF{}, kt, false, F_{});
+            phase(I2{}, OPC{}, WN_{}, WN_{}, kt, false, F_{});
+            phase(I3{}, OPC{}, WF{}, WF{}, kt, false, F_{});
+            next_stage();
+        }
+        // K-steps nk - 2, nk - 1.  In the last six phases the op to issue belongs to the next tile (its ops 0 .. 5: K-step 0
+        // whole, A0 and B0 of K-step 1): same schedule, one op per phase and one wait count, only the descriptor is selected.
+        // Behind the workgroup's last tile those descriptors have no records: the six ops write zeros into free halves.
+        // (A loop of its own rather than straight-line code: peeled in front of the epilogue it spilled accumulators.)
+#pragma clang loop unroll(disable)
+        for (; kt < nk; ++kt) {
+            phase(I0{}, OPX{}, WF{}, WF{}, kt, false, F_{});
+            phase(I1{}, OPX{}, WF{}, WF{}, kt, false, F_{});
+            phase(I2{}, OPX{}, WN_{}, WN_{}, kt, false, F_{});
+            phase(I3{}, OPX{}, WF{}, WF{}, kt, false, F_{});
+            next_stage();
+        }
+        // re-align the wave groups for the epilogue (staggered, waves 4-7 would sit in their last barrier through the epilogue
+        // of waves 0-3 and run theirs afterwards: the two epilogues one after the other, measured +2 .. 7 us per tile)
+        NRV_TILE_STAMP();            // [2 + 4 i] K loop done
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        NRV_TILE_STAMP();            // [3 + 4 i] wave groups re-aligned
+        // epilogue patches: waves 0-3 behind the stage buffers, waves 4-7 in the A1 half of the stage the last K-step used
+        // (after next_stage() that is the buffer the read addresses do NOT point at)
+        {
+            const unsigned ybase = dstg > 0 ? (unsigned)STG : 0u;
+            char* patch = smem + ((PATCH_BEHIND || wr == 0) ? 2 * STG + wave * 4096 : (int)ybase + AH + wc * 4096);
+            const int row_base = cur.m0 + wr * (C::MI * 16), col_base = cur.n0 + wc * 64;
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));        // opaque per tile: the epilogue's per-lane offsets are recomputed here, not kept in registers through the K loops
+            epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, reinterpret_cast<float*>(patch), p.e, row_base, col_base, lane_e);
+            count_stores = M - row_base >= C::MI * 16 && N - col_base >= 64 && (EPI != NRV_EPI_BIAS_GELU || p.e.aux_out != nullptr);
+        }
+        NRV_TILE_STAMP();            // [4 + 4 i] epilogue issued
+        if (!has_next) break;
+        if (wr == 1) __builtin_amdgcn_s_barrier();                  // stagger again: waves 4-7 one barrier behind
+        kb = (kb + nk) & 1;
+        cur = nxt;
+        t = tnext;
     }
-    // K-step nk - 2: ops B1, A1 of the last K-step are the last ones
-    phase(I0{}, T{}, WF{}, kt);
-    phase(I1{}, T{}, WF{}, kt);
-    phase(I2{}, F{}, WN_{}, kt);
-    phase(I3{}, F{}, WT2{}, kt);
-    next_stage();
-    ++kt;
-    phase(I0{}, F{}, WT1{}, kt);
-    phase(I1{}, F{}, W0{}, kt);
-    phase(I2{}, F{}, WN_{}, kt);
-    phase(I3{}, F{}, WN_{}, kt);
-    if (wr == 0) __builtin_amdgcn_s_barrier();                      // re-align the wave groups
-    NRV_STAMP(2);
-    // the last barrier passed by waves 4-7 closes their last MFMA section: the tile buffers are free for the epilogue patches
-    epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, smem, p.e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // stamp hooks below are empty in the product
-    NRV_STAMP(3);
-    NRV_STAMP_FLUSH_WG(4, tid);
+    NRV_TILE_STAMP();                // last: stores drained
     NRV_WACC_FLUSH(C::NWAVES, wave, lane);
 }
 
@@ -964,7 +1105,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
     }
     EpiParams e = p.e;
     e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
-    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, smem, e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane, wave);
+    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, reinterpret_cast<float*>(smem + wave * EPI_PATCH_BYTES), e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1216,7 +1357,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));            // keeps the epilogue's per-lane address arithmetic below the K loop
-    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, smem, e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane_e, wave);
+    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, reinterpret_cast<float*>(smem + wave * EPI_PATCH_BYTES), e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane_e);
 }
 
 // C = beta * C + sum_s slab[s].  A block of 4 waves owns 64 consecutive 16-byte chunks of C; wave g sums the slabs
@@ -1283,14 +1424,22 @@ int launch_nt_cfg(GemmNTParams p, hipStream_t s) {
     return 0;
 }
 
+int device_cus();
+
 template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt8_cfg(GemmNTParams p, hipStream_t s) {
-    static int attr = set_lds(gemm_nt8_kernel<C, EPI, OUT_F32, AUX_F32>, C::LDS);
+    constexpr int LDS = nt8_lds_bytes<C>();
+    static int attr = set_lds(gemm_nt8_kernel<C, EPI, OUT_F32, AUX_F32>, LDS);
     if (attr != 0) return attr;
     const int tiles_m = (int)nrv_cdiv(p.e.M, C::TBM), tiles_n = (int)nrv_cdiv(p.e.N, C::TBN);
     p.tiles_n = tiles_n;
     p.gn = 4;
-    hipLaunchKernelGGL((gemm_nt8_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS, s, p);
+    p.ntiles = tiles_m * tiles_n;
+    // persistent: one workgroup per CU walks the tiles b, b + grid, ... (the grid stays a multiple of the 8 XCDs so that a
+    // workgroup's tiles stay on its XCD's share of the tile order)
+    const int cus = device_cus() & ~7;
+    const int grid = NRV_TUNE_NT8_GRID(p.ntiles < cus || cus <= 0 ? p.ntiles : cus, p.ntiles);      // identity in the product (csrc/nrv_dev.hpp)
+    hipLaunchKernelGGL((gemm_nt8_kernel<C, EPI, OUT_F32, AUX_F32>), dim3(grid), dim3(C::THREADS), LDS, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }

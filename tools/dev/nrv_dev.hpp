@@ -44,6 +44,8 @@ extern "C" int NRV_DEV_CAT(nrv_dev_read_stamps_, NRV_DEV_TU)(unsigned long long*
 #define NRV_WACC_FLUSH(nwaves, wave, lane)
 #define NRV_STAMP_SEQ_VARS(tid)
 #define NRV_STAMP_SEQ()
+#define NRV_TILE_STAMP_VARS(tid)
+#define NRV_TILE_STAMP()
 #else
 #define NRV_STAMP_VARS(n) unsigned long long nrv_t_[n] = {}
 #define NRV_STAMP(i) do { nrv_t_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
@@ -79,9 +81,27 @@ extern "C" int NRV_DEV_CAT(nrv_dev_read_stamps_, NRV_DEV_TU)(unsigned long long*
         ++nrv_sq_i_;                                                                                                    \
     } while (0)
 #endif
+// tile stamps (persistent kernels): buf[2^20 + 32 * blockIdx.x + k] = s_memrealtime (100 MHz) of the k-th NRV_TILE_STAMP() of wave 0, k < 32.
+// `wave` is wave-uniform (readfirstlane) and all 64 lanes store the same value: a thread-0 branch in the tile loop made hipcc treat
+// the loop-carried tile descriptors as divergent (vector registers, which the LDS-DMA asm cannot take)
+#ifndef NRV_DEV_NO_STAMPS
+#define NRV_TILE_STAMP_VARS(wave) const bool nrv_ts_on_ = nrv_dev_buf && (wave) == 0; int nrv_ts_i_ = 0
+#define NRV_TILE_STAMP()                                                                                                \
+    do {                                                                                                                \
+        if (nrv_ts_on_ && nrv_ts_i_ < 32)                                                                               \
+            nrv_dev_buf[(1u << 20) + (unsigned long long)blockIdx.x * 32 + nrv_ts_i_] = __builtin_amdgcn_s_memrealtime(); \
+        ++nrv_ts_i_;                                                                                                    \
+    } while (0)
+#endif
 // tile sweep builds: python tools/build_dev.py t256 --instrument -DNRV_DEV_NO_STAMPS -DNRV_FORCE_NT_TILE=256   (128 / 192 / 256 / 320 / 1384)
 #ifdef NRV_FORCE_NT_TILE
 #define NRV_TUNE_NT_TILE(choice) (NRV_FORCE_NT_TILE)
 #else
 #define NRV_TUNE_NT_TILE(choice) (choice)
+#endif
+// persistent NT kernel launched with one workgroup per tile (no hand-over between tiles): -DNRV_FORCE_NT8_ONE_TILE
+#ifdef NRV_FORCE_NT8_ONE_TILE
+#define NRV_TUNE_NT8_GRID(grid, ntiles) (ntiles)
+#else
+#define NRV_TUNE_NT8_GRID(grid, ntiles) (grid)
 #endif
