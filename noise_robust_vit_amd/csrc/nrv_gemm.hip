@@ -1128,6 +1128,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    NRV_WACC_VARS;                   // hooks: empty in the product (csrc/nrv_dev.hpp)
 
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
     const int split = id / p.tiles_mn;
@@ -1266,10 +1267,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
             else if constexpr (P == 2) stage(I0{}, kt + 2);
             else stage(I2{}, kt + 2);
         }
+        NRV_WACC(4 * P + 0);                                      // sections as in gemm_nt8_kernel: reads + DMA issue
         if constexpr (WAIT >= 0) wait_vm<WAIT>();
+        NRV_WACC(4 * P + 1);                                      // counted vmcnt wait
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        NRV_WACC(4 * P + 2);                                      // barrier + fragment-read latency
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MF) {
             constexpr int mh = (P >= 2) ? MH : 0;
@@ -1300,6 +1304,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        NRV_WACC(4 * P + 3);                                      // MFMA section + closing barrier
     };
     using T = std::true_type; using F = std::false_type;
     using WN_ = std::integral_constant<int, -1>;
@@ -1321,6 +1326,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     wait_vm<3 * NA + 3 * NB>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
+    NRV_WACC_MARK();
 
     const int nmain = nk - 2;
     int kt = 0;
@@ -1345,6 +1351,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     phase(I2{}, I1{}, F{}, WN_{}, T{}, T{}, kt);
     phase(I3{}, I1{}, F{}, WN_{}, F{}, T{}, kt);
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    NRV_WACC_FLUSH(8, wave, lane);
 
     if (do_bias && lane < 16) {
 #pragma unroll
