@@ -112,11 +112,11 @@ def test_gemm_nt_plain(dev, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(9000, 2048, 192), (50432, 768, 768), (20000, 3072, 192), (50000, 1000, 704)])
 def test_gemm_nt_persistent_workgroups_every_tile_every_time(dev, M, N, K):
     """More tiles than CUs: a workgroup of the persistent NT kernel walks several tiles, the next tile's first operands land
-    in LDS while the current tile's epilogue stores are issued.  Every element of every tile, five times in a row, for the fp32,
-    fp32-residual and gelu epilogues: an intermittent fault of this kind was a store whose data registers were overwritten two
+    in LDS while the current tile's epilogue stores are issued.  Every element of every tile, five times in a row, for every
+    epilogue: an intermittent fault of this kind was a store whose data registers were overwritten two
     instructions later (element 1 of a pass replaced by a row index in a few slabs, csrc/nrv_gemm.hip store_b128_row)."""
     k = _k()
-    from noise_robust_vit_amd._lib import EPI_BIAS_GELU, EPI_BIAS_RESIDUAL
+    from noise_robust_vit_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU
     A = rnd((M, K), dev, 40, 0.5)
     B = rnd((N, K), dev, 41, 0.5)
     bias = rnd((N,), dev, 42, 1.0, torch.float32)
@@ -133,12 +133,18 @@ def test_gemm_nt_persistent_workgroups_every_tile_every_time(dev, M, N, K):
         assert not bad.any(), (rep, int(bad.sum()), bad.nonzero()[:4].tolist())
         u = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         h = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=bias, aux_out=u)
+        cb = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, bias=bias)
+        dd = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
         if first is None:
-            first = (c.clone(), y.clone(), h.clone(), u.clone())
+            first = (c.clone(), y.clone(), h.clone(), u.clone(), cb.clone(), dd.clone())
             want = torch.nn.functional.gelu(ref + bias)
             assert ((h.float() - want).abs() <= want.abs() * 2 ** -7 + 2e-3 * float(want.abs().max())).all()
+            wb = ref + bias
+            assert ((cb.float() - wb).abs() <= wb.abs() * 2 ** -8 + 1e-3 * float(wb.abs().max())).all()
+            wd = ref * u.float()
+            assert ((dd.float() - wd).abs() <= wd.abs() * 2 ** -8 + 1e-3 * float(wd.abs().max())).all()
         else:                                          # same launch, same summation order: bit-identical
-            for got, exp in zip((c, y, h, u), first):
+            for got, exp in zip((c, y, h, u, cb, dd), first):
                 assert torch.equal(got, exp), rep
 
 
