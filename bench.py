@@ -197,7 +197,11 @@ def main():
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient exchange precision (N > 1)")
     ap.add_argument("--bucket-mib", type=float, default=64.0, help="all-reduce bucket size")
     ap.add_argument("--tail-mib", type=float, default=8.0, help="cap of the last (non-overlappable) bucket")
-    ap.add_argument("--rccl-max-ctas", type=int, default=0, help="CU budget of RCCL's kernels (0: RCCL default)")
+    ap.add_argument("--rccl-max-ctas", type=int, default=-1,
+                    help="CU budget of RCCL's kernels (-1: 8 when N > 1 -- the 605 MB a ViT-B/16 step exchanges per GPU hide behind a 33 ms "
+                         "backward at a fraction of the xGMI rate --, 0: RCCL's default)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="CUs the GEMM launches leave free for the collective's kernels when N > 1 (-1: the RCCL budget; 0: none)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (Trainer.capture)")
     args = ap.parse_args()
 
@@ -224,6 +228,10 @@ def main():
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if args.rccl_max_ctas < 0:
+            args.rccl_max_ctas = 8 if world > 1 else 0
+        if args.reserve_cus < 0:
+            args.reserve_cus = args.rccl_max_ctas if world > 1 else 0
         pg_desc = make_process_group(rank, world, device=dev, backend="nccl", max_ctas=args.rccl_max_ctas)   # "nccl" IS RCCL on ROCm
 
     kind = ARCHS[args.arch][0]
@@ -231,7 +239,7 @@ def main():
     model = build_model(args.arch, robust=args.robust).to(dev).train()
     # under the launcher the collectives are issued at any world size (world 1: a one-rank RCCL group, same calls)
     reducer = GradReducer(model, world, force_collectives=world == 1, bucket_mib=args.bucket_mib, tail_mib=args.tail_mib,
-                          grad_dtype=args.grad_dtype) if use_pg else None
+                          grad_dtype=args.grad_dtype, reserve_cus=max(args.reserve_cus, 0)) if use_pg else None
     compute_loss = (lambda m, xb, yb: m(xb)) if kind == "mae" else None
     trainer = Trainer(model, TrainConfig(lr=5e-4, weight_decay=0.05, grad_max_norm=5.0, noise_std=args.noise_std), reducer,
                       compute_loss=compute_loss)
@@ -290,7 +298,8 @@ def main():
                    "step": ("fwd + MSE on masked patches" if kind == "mae" else "fwd + CE(ls=0.1)") + " + bwd + allreduce + clip(5.0) + AdamW",
                    "collectives": ("none (single process, no process group)" if not use_pg else
                                    f"rccl all_reduce(AVG) of {args.grad_dtype} gradients per {args.bucket_mib:g} MiB bucket (last bucket <= "
-                                   f"{args.tail_mib:g} MiB; buckets {[round(b / 2**20, 1) for b in reducer.bucket_bytes()]} MiB); {pg_desc}"
+                                   f"{args.tail_mib:g} MiB; buckets {[round(b / 2**20, 1) for b in reducer.bucket_bytes()]} MiB); {pg_desc}; "
+                                   f"GEMM launches planned for the device's CUs minus {reducer.reserve_cus}"
                                    + (", forced at world 1" if world == 1 else ", overlapped with backward")),
                    "launch": "one HIP graph per step (Trainer.capture)" if args.graph else "eager (one C-ABI call per kernel)",
                    "streams": "weight-gradient GEMMs on a second HIP stream where the dX grid leaves >= 15 % of its CU-rounds idle "

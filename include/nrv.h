@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 9
+#define NRV_ABI_VERSION 10
 
 /* dtype codes */
 #define NRV_F32 0
@@ -234,6 +234,14 @@ int nrv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, size_t
 int nrv_adamw_f32(float* p, const float* grad, float* m, float* v, int64_t n,
                   double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                   const float* gnorm_sq, float max_norm, const float* step_scalars, void* stream);
+
+/* CUs the GEMM launches leave free (process-wide; default 0; returns the previous value, or a negative error code when n is
+ * negative or leaves fewer than 8 CUs).  The NT GEMM is persistent (one workgroup per CU for the whole launch) and the TN
+ * GEMM sizes its token splits to one round of the CUs: with a collective's kernels resident on some CUs (RCCL all-reduce
+ * overlapped with the backward, parallel.GradReducer) a grid sized for ALL CUs runs its last workgroups in a second round,
+ * i.e. takes twice as long.  With n > 0 both kernels plan for (CUs - n).  Single-GPU runs never call this.
+ * A different value changes the TN split count, hence the summation order of weight gradients (deterministic per value). */
+int nrv_set_reserved_cus(int n);
 
 /* Hardware-assumption probes used by tests/test_kernels_gpu.py (test_probe_*) (MFMA lane maps, transposed LDS read,
  * LDS-DMA layout and out-of-range zero fill).  out: fp32 scratch written by a single wave. */

@@ -18,7 +18,7 @@ LIB_PATH = _DEFAULT_LIB       # no environment override: what runs is the in-tre
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -59,6 +59,7 @@ SIGNATURES = {
                               c_double, c_double, c_double, c_double, c_double, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "nrv_sinkhorn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "nrv_sinkhorn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "nrv_set_reserved_cus": (c_int, [c_int]),
     "nrv_probe": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p]),
 }
 

@@ -20,6 +20,7 @@
 // Reference call sites replaced: simple_vit.py:39,41,61,62,130 ; vit.py:40-47 ; utils.py:115,579.
 
 #include "nrv_common.hpp"
+#include <atomic>
 #include <type_traits>
 #define NRV_DEV_TU gemm
 #include <nrv_dev.hpp>       // instrumentation hooks: empty in the product (csrc/nrv_dev.hpp)
@@ -1451,8 +1452,9 @@ int launch_nt8_cfg(GemmNTParams p, hipStream_t s) {
     return 0;
 }
 
-// tile selection
-int device_cus() {
+// tile selection.  device_cus(): the CUs the GEMM launches plan for = the device's CUs minus nrv_set_reserved_cus()
+std::atomic<int> g_reserved_cus{0};
+int physical_cus() {
     static int n = [] {
         int dev = 0, v = 256;
         hipDeviceProp_t prop;
@@ -1460,6 +1462,10 @@ int device_cus() {
         return v > 0 ? v : 256;
     }();
     return n;
+}
+int device_cus() {
+    const int v = physical_cus() - g_reserved_cus.load(std::memory_order_relaxed);
+    return v > 8 ? v : 8;
 }
 
 int nt_tile_choice(int64_t M, int64_t N, int64_t K, bool allow_384n) {
@@ -1588,6 +1594,11 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
         default:
             return NRV_ERR_EPILOGUE;
     }
+}
+
+extern "C" int nrv_set_reserved_cus(int n) {
+    if (n < 0 || physical_cus() - n < 8) return NRV_ERR_SHAPE;
+    return g_reserved_cus.exchange(n, std::memory_order_relaxed);
 }
 
 extern "C" size_t nrv_gemm_tn_workspace(int64_t M, int64_t N, int64_t T) {

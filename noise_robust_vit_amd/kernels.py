@@ -61,6 +61,14 @@ def _workspace(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+def set_reserved_cus(n: int) -> int:
+    """CUs the GEMM launches leave free for a collective's kernels (include/nrv.h); returns the previous value."""
+    prev = _lib.load().nrv_set_reserved_cus(int(n))
+    if prev < 0:
+        check(prev, "nrv_set_reserved_cus")
+    return prev
+
+
 # ----------------------------------------------------------------------------------------------
 # optional per-launch timing (bench.py's roofline leg): HIP events on the stream the kernel runs on
 # ----------------------------------------------------------------------------------------------

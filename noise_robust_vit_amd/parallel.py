@@ -62,7 +62,8 @@ def make_process_group(rank: int, world: int, device=None, backend: str = "nccl"
 class GradReducer:
     def __init__(self, model: torch.nn.Module, world: int, bucket_mib: float = 64.0,
                  process_group=None, attach: bool = True, sync_params: bool = True,
-                 force_collectives: bool = False, grad_dtype: str = "fp32", tail_mib: float = 8.0) -> None:
+                 force_collectives: bool = False, grad_dtype: str = "fp32", tail_mib: float = 8.0,
+                 reserve_cus: int = 0) -> None:
         """`sync_params`: broadcast rank 0's parameters and buffers at construction, as DistributedDataParallel does
         (examples/CIFAR100.py:206-208 wraps the model in DDP): replicas start identical whatever each rank's seed was.
         `force_collectives`: issue every bucket's all-reduce even when world == 1 (a single-GPU RCCL process group
@@ -70,7 +71,11 @@ class GradReducer:
         `grad_dtype`: "fp32" (default, exact mean of the ranks' fp32 gradients) or "bf16" (each rank's bucket is rounded to
         bf16 before the reduction: 8 significant bits per addend, relative error of the mean <= 2^-8 per element -- the size of
         the rounding the bf16 GEMM operands already carry; tests/test_parallel_gloo.py states the measured cost).
-        `tail_mib`: upper bound of the last bucket in backward order (0: no cap)."""
+        `tail_mib`: upper bound of the last bucket in backward order (0: no cap).
+        `reserve_cus`: CUs the GEMM launches leave to the collective's kernels (`nrv_set_reserved_cus`, process-wide; only
+        with world > 1 on the HIP device).  The NT GEMM holds one workgroup on every CU it plans for during a whole launch and
+        the TN GEMM sizes its splits to one round of them: planned for all 256 with RCCL's kernels resident on some, their
+        last workgroups would run in a second round.  Pair it with `make_process_group(max_ctas=...)`."""
         if grad_dtype not in ("fp32", "bf16"):
             raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
         self.world = world
@@ -80,6 +85,10 @@ class GradReducer:
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
+        self.reserve_cus = int(reserve_cus) if (world > 1 and params[0].is_cuda) else 0
+        if self.reserve_cus > 0:
+            from . import kernels as K
+            K.set_reserved_cus(self.reserve_cus)
         if sync_params and world > 1 and dist.is_initialized():
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):

@@ -639,3 +639,29 @@ def test_sinkhorn_module_forward_backward(dev, shape, iters):
     (Pr * W.double()).sum().backward()
     rel = ((S.grad.double() - Sr.grad).norm() / Sr.grad.norm().clamp_min(1e-30)).item()
     assert rel < 2e-4, rel
+
+
+def test_gemms_planned_for_fewer_cus_stay_correct(dev):
+    """nrv_set_reserved_cus: with CUs left to a collective the persistent NT grid and the TN split count shrink; results stay
+    within the same bounds (NT: same K order, bit-identical; TN: another split count, another summation order)."""
+    k = _k()
+    A = rnd((9000, 768), dev, 50, 0.5)
+    B = rnd((2304, 768), dev, 51, 0.5)
+    X = rnd((9000, 512), dev, 52, 0.5)
+    c0 = k.gemm_nt(A, B, out_dtype=torch.float32)
+    w0 = k.gemm_tn(A, X)
+    prev = k.set_reserved_cus(16)
+    try:
+        assert prev == 0
+        c1 = k.gemm_nt(A, B, out_dtype=torch.float32)
+        w1 = k.gemm_tn(A, X)
+    finally:
+        assert k.set_reserved_cus(0) == 16
+    assert torch.equal(c0, c1)
+    ref = A.float().t() @ X.float()
+    assert rel_err(w0, ref) < 1e-5 * math.sqrt(9000) and rel_err(w1, ref) < 1e-5 * math.sqrt(9000)
+    with pytest.raises(Exception):
+        k.set_reserved_cus(-1)
+    with pytest.raises(Exception):
+        k.set_reserved_cus(10 ** 6)
+    assert k.set_reserved_cus(0) == 0
