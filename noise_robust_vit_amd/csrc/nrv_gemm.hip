@@ -1268,13 +1268,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
             else if constexpr (P == 2) stage(I0{}, kt + 2);
             else stage(I2{}, kt + 2);
         }
-        NRV_WACC(4 * P + 0);                                      // sections as in gemm_nt8_kernel: reads + DMA issue
+        NRV_WACC(4 * P + 0);                                      // section 0: fragment reads + DMA issue
         if constexpr (WAIT >= 0) wait_vm<WAIT>();
-        NRV_WACC(4 * P + 1);                                      // counted vmcnt wait
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        NRV_WACC(4 * P + 2);                                      // barrier + fragment-read latency
+        NRV_WACC(4 * P + 2);                                      // section 2: counted vmcnt wait + barrier + fragment-read latency
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MF) {
             constexpr int mh = (P >= 2) ? MH : 0;
@@ -1287,6 +1286,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
 #pragma unroll
                     for (int nl = 0; nl < 2; ++nl)
                         acc[mh + ml][nh + nl] = mfma16(bs[bq][nl][ks], a[ml][ks], acc[mh + ml][nh + nl]);
+            NRV_WACC(4 * P + 1);                                  // section 1: the quadrant's 16 MFMAs issued
             if constexpr (P == 0 || P == 2) {
                 if (do_bias && (wc >> 1) == P / 2) {              // uniform
                     if (wc & 1) {
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        NRV_WACC(4 * P + 3);                                      // MFMA section + closing barrier
+        NRV_WACC(4 * P + 3);                                      // section 3: bias-gradient MFMAs + closing barrier
     };
     using T = std::true_type; using F = std::false_type;
     using WN_ = std::integral_constant<int, -1>;
