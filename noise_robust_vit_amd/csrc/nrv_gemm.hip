@@ -1477,7 +1477,11 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K, bool allow_384n) {
     const int64_t cus = device_cus();
     const int64_t tn = nrv_cdiv(N, 256);
     static const int heights[4] = {256, 320, 192, 128};          // ties go to the earlier entry
-    static const double per_tile[4] = {256.0 + 64.0, (320.0 + 64.0) * 1.01, 192.0 + 64.0, 128.0 + 64.0};
+    // the 320-row tile's K-step is 1.41 x the 256-row tile's (3 280 vs 2 330 cycles: its fragment reads and three-piece A ops
+    // fill the issue slots), its epilogue 1.25 x: 1.3 per tile, refitted on the sweep with the persistent kernel
+    // (profiles/r03_nt_tile_sweep.txt: with the round-2 ratio 1.21 fc1 / dU of ViT-B and four ViT-S / MAE shapes took the 320-row tile
+    // and lost 2 - 4 % to the 256-row one)
+    static const double per_tile[4] = {256.0 + 64.0, (256.0 + 64.0) * 1.3, 192.0 + 64.0, 128.0 + 64.0};
     int best = 256;
     double best_cost = 0.0;
     for (int i = 0; i < 4; ++i) {

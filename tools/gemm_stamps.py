@@ -20,7 +20,7 @@ T = int(os.environ.get("T", 50432))
 
 def tile_rows(M, N):
     tn = -(-N // 256)
-    cands = [(256, 320.0), (320, 384.0 * 1.01), (192, 256.0), (128, 192.0)]      # nt_tile_choice (nrv_gemm.hip)
+    cands = [(256, 320.0), (320, 320.0 * 1.3), (192, 256.0), (128, 192.0)]      # nt_tile_choice (nrv_gemm.hip)
     best = None
     for h, pt in cands:
         c = math.ceil(-(-M // h) * tn / 256) * pt
