@@ -17,3 +17,4 @@
 #define NRV_TILE_STAMP()
 #define NRV_TUNE_NT_TILE(choice) (choice)      // tile-height override of the instrumented header (tools/tile_sweep.py)
 #define NRV_TUNE_NT8_GRID(grid, ntiles) (grid)  // workgroups of the persistent NT kernel (override: one tile per workgroup)
+#define NRV_TUNE_STAGGER(cond) (cond)             // the wave-group stagger of the phased K loops (override: both groups in phase)

@@ -844,7 +844,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     stage(I0{}, cur, 0, 0); stage(I1{}, cur, 0, 0); stage(I2{}, cur, 0, 0); stage(I3{}, cur, 0, 0); stage(I0{}, cur, 1, 1); stage(I1{}, cur, 1, 1);
     wait_vm<W4>();
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();                      // stagger: waves 4-7 one barrier behind
+    if (NRV_TUNE_STAGGER(wr == 1)) __builtin_amdgcn_s_barrier();                      // stagger: waves 4-7 one barrier behind
     NRV_WACC_MARK();
 
     bool count_stores = false;       // the previous epilogue of this wave issued exactly E_OPS counted instructions
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         // re-align the wave groups for the epilogue (staggered, waves 4-7 would sit in their last barrier through the epilogue
         // of waves 0-3 and run theirs afterwards: the two epilogues one after the other, measured +2 .. 7 us per tile)
         NRV_TILE_STAMP();            // [2 + 4 i] K loop done
-        if (wr == 0) __builtin_amdgcn_s_barrier();
+        if (NRV_TUNE_STAGGER(wr == 0)) __builtin_amdgcn_s_barrier();
         NRV_TILE_STAMP();            // [3 + 4 i] wave groups re-aligned
         // epilogue patches: waves 0-3 behind the stage buffers, waves 4-7 in the A1 half of the stage the last K-step used
         // (after next_stage() that is the buffer the read addresses do NOT point at)
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         }
         NRV_TILE_STAMP();            // [4 + 4 i] epilogue issued
         if (!has_next) break;
-        if (wr == 1) __builtin_amdgcn_s_barrier();                  // stagger again: waves 4-7 one barrier behind
+        if (NRV_TUNE_STAGGER(wr == 1)) __builtin_amdgcn_s_barrier();                  // stagger again: waves 4-7 one barrier behind
         kb = (kb + nk) & 1;
         cur = nxt;
         t = tnext;
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     stage(I1{}, 0); stage(I0{}, 0); stage(I2{}, 0); stage(I3{}, 0); stage(I1{}, 1); stage(I0{}, 1); stage(I2{}, 1);
     wait_vm<3 * NA + 3 * NB>();
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();
+    if (NRV_TUNE_STAGGER(wr == 1)) __builtin_amdgcn_s_barrier();
     NRV_WACC_MARK();
 
     const int nmain = nk - 2;
@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     phase(I1{}, I1{}, F{}, W0{}, T{}, T{}, kt);
     phase(I2{}, I1{}, F{}, WN_{}, T{}, T{}, kt);
     phase(I3{}, I1{}, F{}, WN_{}, F{}, T{}, kt);
-    if (wr == 0) __builtin_amdgcn_s_barrier();
+    if (NRV_TUNE_STAGGER(wr == 0)) __builtin_amdgcn_s_barrier();
     NRV_WACC_FLUSH(8, wave, lane);
 
     if (do_bias && lane < 16) {

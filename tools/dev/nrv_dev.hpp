@@ -105,3 +105,9 @@ extern "C" int NRV_DEV_CAT(nrv_dev_read_stamps_, NRV_DEV_TU)(unsigned long long*
 #else
 #define NRV_TUNE_NT8_GRID(grid, ntiles) (grid)
 #endif
+// phased K loops without the wave-group stagger (waves 4-7 in phase with waves 0-3): -DNRV_FORCE_NO_STAGGER
+#ifdef NRV_FORCE_NO_STAGGER
+#define NRV_TUNE_STAGGER(cond) (false)
+#else
+#define NRV_TUNE_STAGGER(cond) (cond)
+#endif
