@@ -123,12 +123,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned rawx2_t;
 // storing, LDS-DMA of the next tile in flight) an immediately following VALU write of a data register did reach the store:
 // element 1 of an fp32 pass came out as the next pass's row index, intermittently (tools/nt_diag.py; first seen with the
 // persistent kernel, latent in every build before it).  The data registers stay live across two wait states behind the store.
+// AUX = 2: non-temporal (the gelu' stream: written once per layer, next read in the backward pass a whole model later)
+template <int AUX = 0>
 __device__ __forceinline__ void store_b128_row(rawx4_t v, __amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, AUX);
     asm volatile("s_nop 1" :: "v"(v) : "memory");
 }
+template <int AUX = 0>
 __device__ __forceinline__ void store_b64_row(rawx2_t v, __amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, AUX);
     asm volatile("s_nop 1" :: "v"(v) : "memory");
 }
 
@@ -201,13 +204,14 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
                         const int r0 = mi * 16 + RPI * i;                // first row of the pass (uniform)
                         const int so = (r0 < rows_here ? r0 : 0) * a_rs;  // keep soffset inside the records; the lanes are dropped below
                         const unsigned vo = r0 < rows_here ? a_vo : NRV_OOB;
+                        constexpr int LAUX = EPI == NRV_EPI_DGELU ? 2 : 0;      // the gelu' stream is read once: non-temporal
                         if (AW == 2) {
-                            const rawx2_t t = __builtin_amdgcn_raw_buffer_load_b64(ra, vo, so, 0);
+                            const rawx2_t t = __builtin_amdgcn_raw_buffer_load_b64(ra, vo, so, LAUX);
                             auxr[mh][i][0] = t[0]; auxr[mh][i][1] = t[1];
                         } else {
 #pragma unroll
                             for (int q = 0; q < AW / 4; ++q) {
-                                const rawx4_t t = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + 16 * q, so, 0);
+                                const rawx4_t t = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + 16 * q, so, LAUX);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) auxr[mh][i][4 * q + j] = t[j];
                             }
@@ -269,10 +273,10 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
                         if (EPI == NRV_EPI_BIAS_GELU && want_u) {
                             if (V == 2) {
                                 const rawx4_t o = {pku[0], pku[1], pku[2 * V - 2], pku[2 * V - 1]};
-                                store_b128_row(o, ru, u_vo, r0 * u_rs);
+                                store_b128_row<2>(o, ru, u_vo, r0 * u_rs);
                             } else {
                                 const rawx2_t o = {pku[0], pku[1]};
-                                store_b64_row(o, ru, u_vo, r0 * u_rs);
+                                store_b64_row<2>(o, ru, u_vo, r0 * u_rs);
                             }
                         }
                     }

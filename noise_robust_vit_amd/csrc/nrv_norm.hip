@@ -29,6 +29,17 @@ __device__ __forceinline__ f32x4_t load4(const void* base, long long idx) {
         return f32x4_t{bf16lo_to_f32(a[0]), bf16hi_to_f32(a[0]), bf16lo_to_f32(a[1]), bf16hi_to_f32(a[1])};
     }
 }
+// the same, non-temporal: streams read for the LAST time (the backward's x, dy and residual-gradient reads) do not displace
+// the weights and operand panels the neighbouring GEMMs keep in L2 / the Infinity Cache
+template <bool F32>
+__device__ __forceinline__ f32x4_t load4_nt(const void* base, long long idx) {
+    if (F32) {
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(base) + idx));
+    } else {
+        const u32x2_t a = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(base) + idx));
+        return f32x4_t{bf16lo_to_f32(a[0]), bf16hi_to_f32(a[0]), bf16lo_to_f32(a[1]), bf16hi_to_f32(a[1])};
+    }
+}
 __device__ __forceinline__ void store4_bf16(bf16_t* base, long long idx, f32x4_t v) {
     u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     *reinterpret_cast<u32x2_t*>(base + idx) = pk;
@@ -131,8 +142,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
         for (int j = 0; j < MAXJ; ++j) {
             const int c = (l + LPR * j) * 4;
             if (ok && c < dim) {
-                const f32x4_t d = load4<false>(dy, row * dim + c);
-                xh[j] = (load4<X_F32>(x, row * dim + c) - mu) * rs;
+                const f32x4_t d = load4_nt<false>(dy, row * dim + c);
+                xh[j] = (load4_nt<X_F32>(x, row * dim + c) - mu) * rs;
                 g[j] = d * g4[j];
                 c1 += sum4(g[j] * xh[j]);
                 c2 += sum4(g[j]);
@@ -150,8 +161,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
             const int c = (l + LPR * j) * 4;
             if (ok && c < dim) {
                 f32x4_t d = (g[j] - c2 - xh[j] * c1) * rs;
-                if (DRES == 1) d += load4<true>(dres, row * dim + c);
-                if (DRES == 2) d += load4<false>(dres, row * dim + c);
+                if (DRES == 1) d += load4_nt<true>(dres, row * dim + c);
+                if (DRES == 2) d += load4_nt<false>(dres, row * dim + c);
                 if (dx_f32 != nullptr) *reinterpret_cast<f32x4_t*>(dx_f32 + row * dim + c) = d;
                 if (dx_bf16 != nullptr) store4_bf16(dx_bf16, row * dim + c, d);
             }
