@@ -54,7 +54,13 @@ def make_process_group(rank: int, world: int, device=None, backend: str = "nccl"
     if device is not None and backend == "nccl":
         args["device_id"] = device
     if opts is not None:
-        args["pg_options"] = opts
+        try:
+            dist.init_process_group(backend, pg_options=opts, **args)
+            return desc
+        except (RuntimeError, TypeError, ValueError) as e:       # a build of RCCL / torch without these config fields
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            desc = f"{backend} default communicator config (the requested one was refused: {type(e).__name__})"
     dist.init_process_group(backend, **args)
     return desc
 
