@@ -91,10 +91,10 @@ class GradReducer:
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
+        # applied from the first bucket's all-reduce to the end of the step (_launch / finish_step): the forward pass and the
+        # backward's first layers, which run beside no collective, keep every CU
         self.reserve_cus = int(reserve_cus) if (world > 1 and params[0].is_cuda) else 0
-        if self.reserve_cus > 0:
-            from . import kernels as K
-            K.set_reserved_cus(self.reserve_cus)
+        self._reserved = False
         if sync_params and world > 1 and dist.is_initialized():
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
@@ -235,6 +235,10 @@ class GradReducer:
         if (self.world <= 1 and not self.force) or not dist.is_initialized():
             return
         s, e, _ = self.buckets[b]
+        if self.reserve_cus > 0 and not self._reserved:
+            from . import kernels as K
+            K.set_reserved_cus(self.reserve_cus)
+            self._reserved = True
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         if self.grad_dtype == "bf16":
             # one bf16 slab per bucket in flight (the staging tensors live until finish_step); cast on the compute stream,
@@ -279,6 +283,10 @@ class GradReducer:
         for w in self._works:
             w.wait()
         self._works = []
+        if self._reserved:
+            from . import kernels as K
+            K.set_reserved_cus(0)
+            self._reserved = False
         for s, e, slab in self._stage_slabs:          # reduced bf16 means back into the fp32 buffer the optimizer reads
             self.flat[s:e].copy_(slab)
         self._stage_slabs = []
