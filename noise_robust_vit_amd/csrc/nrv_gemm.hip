@@ -804,7 +804,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
             if constexpr (OP == 1) {
                 stage(KIND{}, cur, kk, par);
             } else {                                              // the op pipeline runs on into the next tile: K-step kk - nk of `nxt`
-                const bool over = kk >= nk;
+                // in the hand-over loop (kt >= nk - 2) phases 2 and 3 always issue for the next tile (kk = kt + 2 >= nk); phases
+                // 0 and 1 do in its second K-step only
+                const bool over = P >= 2 ? true : kk >= nk;
                 constexpr int kind = KIND::value;
                 const __amdgpu_buffer_rsrc_t r = kind == 0 ? (over ? nxt.ra0 : cur.ra0) : kind == 1 ? (over ? nxt.rb0 : cur.rb0)
                                                : kind == 2 ? (over ? nxt.rb1 : cur.rb1) : (over ? nxt.ra1 : cur.ra1);

@@ -7,6 +7,6 @@ mkdir -p $OUT
 cd $ROOT
 timeout -k 10 300 python tools/nt_check.py base 2>&1 | grep -v amdgpu | tee $OUT/p_check.log || exit 1
 only=nt timeout -k 10 400 python tools/gemm_bench.py base,product 5 2>&1 | grep -v amdgpu | tee $OUT/p_bench.log
-for a in ${ARCHS:-vit_b_16}; do
+for a in ${ARCHS:-}; do
   arch=$a timeout -k 10 400 python tools/step_ab.py base,product 5 6 2>&1 | grep -v amdgpu | tee -a $OUT/p_step_ab.log
 done
