@@ -744,6 +744,39 @@ def test_mae_trainer_steps_with_fused_projection_as_a_view_of_the_flat_parameter
         assert rel < 2e-2, (ka, rel)          # three AdamW steps at lr 1e-2: sign-like updates amplify bf16-level gradient noise
 
 
+def test_checkpoint_loaded_into_a_trained_lucid_model_reaches_the_fused_projection(dev):
+    """Under Trainer + FusedAdamW the fused [to_q; to_kv] projection is a zero-copy view of the flat parameter buffer.  A
+    checkpoint loaded AFTER a training step writes the parameters in place (version bump of the Parameters, not of the view):
+    the next forward must use the loaded Q / K / V weights -- it must equal a fresh model loaded with the same checkpoint."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd.encoder import WEIGHTS
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+
+    def make(seed):
+        torch.manual_seed(seed)
+        return ViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256).to(dev)
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 64, 64, generator=g).to(dev)
+    y = torch.randint(0, 10, (4,), generator=g).to(dev)
+    other = {k: v.detach().clone() for k, v in make(21).state_dict().items()}
+    m = make(20).train()
+    tr = Trainer(m, TrainConfig(lr=1e-2, weight_decay=0.05, grad_max_norm=1.0))
+    tr.step(x, y)                                        # stages the bf16 images of the fused view
+    att = m.transformer.layers[0][0]
+    assert att._refresh_fused().data_ptr() == att.to_q.weight.data_ptr()        # view mode
+    m.load_state_dict(other)
+    m.eval()
+    with torch.no_grad():
+        got = m(x)
+    WEIGHTS.clear()
+    fresh = make(22).eval()
+    fresh.load_state_dict(other)
+    with torch.no_grad():
+        want = fresh(x)
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
 def test_lucid_fused_qkv_images_are_cached_and_follow_updates(dev):
     """lucid_vit.Attention feeds the fused QKV GEMM from a persistent [to_q; to_kv] buffer: no cast_transpose per forward
     once staged, and an in-place parameter update (version bump) or a raw-pointer update (FusedAdamW -> refresh_all) is
