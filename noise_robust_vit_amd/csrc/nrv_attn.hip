@@ -106,7 +106,7 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_ke
             const int pos = lane & 7;
             const int c = isv ? ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1)) : (pos ^ ((r >> 1) & 7));
             const unsigned vo = (r < N) ? (unsigned)(r * ldq * 2 + c * 16 + (isv ? 2 : 1) * H * DH * 2) : NRV_OOB;
-            dma16(rs, smem + j * 1024, vo);
+            dma16_nt(rs, smem + j * 1024, vo);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): through the builtin so that hipcc's own counting stays exact

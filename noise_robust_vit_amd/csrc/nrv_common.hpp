@@ -139,6 +139,18 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_bas
         : "memory", "m0");
 }
 
+// the same, non-temporal
+__device__ __forceinline__ void dma16_nt(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_base));
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %1, 0 offen nt lds"
+        :
+        : "v"(voffset), "s"(rsrc), "s"(lds_addr)
+        : "memory", "m0");
+}
+
 // the same with a scalar byte offset added by the memory unit (soffset): a K loop advances the SCALAR and keeps the per-lane
 // offset constant, so a DMA costs no vector-ALU instruction (the range check subtracts soffset from the record count)
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, unsigned voffset, unsigned soffset) {

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restri
         for (int j = 0; j < MAXJ; ++j) {
             const int c = (l + LPR * j) * 4;
             if (ok && c < dim) {
-                v[j] = load4<X_F32>(x, row * dim + c);
+                v[j] = load4_nt<X_F32>(x, row * dim + c);      // the stream's next reader is the residual epilogue four kernels on: by then it is evicted anyway
                 s += sum4(v[j]);
             } else {
                 v[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
