@@ -1402,12 +1402,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (ok) {
             int k = g;
             for (; k + 12 < splits; k += 16) {
-                s0 += *reinterpret_cast<const f32x4_t*>(src + (long long)k * slab_stride);
-                s1 += *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 4) * slab_stride);
-                s2 += *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 8) * slab_stride);
-                s3 += *reinterpret_cast<const f32x4_t*>(src + (long long)(k + 12) * slab_stride);
+                s0 += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + (long long)k * slab_stride));
+                s1 += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + (long long)(k + 4) * slab_stride));
+                s2 += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + (long long)(k + 8) * slab_stride));
+                s3 += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + (long long)(k + 12) * slab_stride));
             }
-            for (; k < splits; k += 4) s0 += *reinterpret_cast<const f32x4_t*>(src + (long long)k * slab_stride);
+            for (; k < splits; k += 4) s0 += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + (long long)k * slab_stride));
         }
         part[g][lane] = (s0 + s1) + (s2 + s3);
         __syncthreads();
@@ -1415,7 +1415,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             f32x4_t s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
             float* dst = C + m * ldc + c;
             if (beta != 0.f) s += *reinterpret_cast<const f32x4_t*>(dst) * beta;
-            *reinterpret_cast<f32x4_t*>(dst) = s;
+            __builtin_nontemporal_store(s, reinterpret_cast<f32x4_t*>(dst));      // the gradient buffer is next read by the clip norm, after the whole backward
         }
         __syncthreads();
     }
