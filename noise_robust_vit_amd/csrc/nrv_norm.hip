@@ -163,7 +163,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
                 f32x4_t d = (g[j] - c2 - xh[j] * c1) * rs;
                 if (DRES == 1) d += load4_nt<true>(dres, row * dim + c);
                 if (DRES == 2) d += load4_nt<false>(dres, row * dim + c);
-                if (dx_f32 != nullptr) *reinterpret_cast<f32x4_t*>(dx_f32 + row * dim + c) = d;
+                // the fp32 stream gradient is next read by the LayerNorm backward of the preceding half, five GEMM-sized kernels on
+                if (dx_f32 != nullptr) __builtin_nontemporal_store(d, reinterpret_cast<f32x4_t*>(dx_f32 + row * dim + c));
                 if (dx_bf16 != nullptr) store4_bf16(dx_bf16, row * dim + c, d);
             }
         }
