@@ -145,7 +145,8 @@ class Trainer:
         return loss
 
     # ---- whole-step HIP graph -------------------------------------------------------------------
-    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2) -> None:
+    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2, debug_dump: Optional[str] = None,
+                _allow_custom_loss: bool = False) -> None:
         """Capture forward + loss + backward + clip + AdamW + weight re-staging (one training step, ~370 - 830 kernel launches)
         into ONE HIP graph; afterwards `step()` copies the batch into the captured input buffers, refreshes three device
         scalars (learning rate, bias corrections) and replays the graph.  What this removes is the host: 13 ms of ctypes /
@@ -157,7 +158,7 @@ class Trainer:
             raise RuntimeError("Trainer.capture needs the MI355X path (FusedAdamW)")
         if self.cfg.cutmix_prob > 0.0:
             raise RuntimeError("Trainer.capture: CutMix draws its box on the host every step and cannot be replayed")
-        if self.compute_loss is not None:
+        if self.compute_loss is not None and not _allow_custom_loss:
             # the MAE step (per-sample random permutation -> library sort -> index gathers) faulted on the GPU in its first
             # replay (profiles/r03_graph_capture_eager_vs_replay_and_mae_fault.txt); only the classification step, whose
             # replay is tested bit-equal to the eager step, is captured
@@ -184,9 +185,13 @@ class Trainer:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        if debug_dump:
+            graph.enable_debug_mode()
         opt.stage_step_scalars(self.cfg.lr)
         with torch.cuda.graph(graph):
             self._gloss = body()
+        if debug_dump:
+            graph.debug_dump(debug_dump)          # hipGraphDebugDotPrint: every node of the captured step
         # roll the state back: nothing above was a training step
         with torch.no_grad():
             opt.param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])

@@ -1,19 +1,15 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv: per kernel (last dispatch of each name), counter values."""
-import csv, sys, collections, re
-path = sys.argv[1]
-rows = list(csv.DictReader(open(path)))
+"""Summarise rocprofv3 --pmc counter_collection.csv: per kernel name, the MEAN counter values over its dispatches (and how many)."""
+import collections, csv, re, sys
+rows = csv.DictReader(open(sys.argv[1]))
 per = collections.OrderedDict()
 for r in rows:
-    name = r["Kernel_Name"]
-    short = re.sub(r"\(anonymous namespace\)::", "", name)
-    short = short[:70]
-    key = (short, r["Dispatch_Id"])
-    per.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
-last = collections.OrderedDict()
-for (short, did), c in per.items():
-    last[short] = c           # keep the last dispatch of each kernel name
-for k, c in last.items():
-    if not any(t in k for t in ("gemm", "attn", "splitk", "ln_", "colsum")): continue
-    print(k)
-    print("   " + "  ".join(f"{n}={v:.4g}" for n, v in sorted(c.items())))
+    short = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])[:90]
+    d = per.setdefault(short, {})
+    d.setdefault(r["Counter_Name"], {})[r["Dispatch_Id"]] = float(r["Counter_Value"])
+for k, c in per.items():
+    if not any(t in k for t in ("gemm", "attn", "splitk", "ln_", "colsum", "sinkhorn")):
+        continue
+    n = max(len(v) for v in c.values())
+    print(f"{k}  [{n} dispatches]")
+    print("   " + "  ".join(f"{name}={sum(v.values()) / len(v):.4g}" for name, v in sorted(c.items())))
