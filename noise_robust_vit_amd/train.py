@@ -145,7 +145,7 @@ class Trainer:
         return loss
 
     # ---- whole-step HIP graph -------------------------------------------------------------------
-    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2, debug_dump: Optional[str] = None,
+    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2, keep_graph: bool = False,
                 _allow_custom_loss: bool = False) -> None:
         """Capture forward + loss + backward + clip + AdamW + weight re-staging (one training step, ~370 - 830 kernel launches)
         into ONE HIP graph; afterwards `step()` copies the batch into the captured input buffers, refreshes three device
@@ -184,14 +184,10 @@ class Trainer:
                 body()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        if debug_dump:
-            graph.enable_debug_mode()
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()   # kept: tools/graph_nodes.py walks the nodes
         opt.stage_step_scalars(self.cfg.lr)
         with torch.cuda.graph(graph):
             self._gloss = body()
-        if debug_dump:
-            graph.debug_dump(debug_dump)          # hipGraphDebugDotPrint: every node of the captured step
         # roll the state back: nothing above was a training step
         with torch.no_grad():
             opt.param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])

@@ -33,13 +33,26 @@ def _bf16(t: Tensor) -> Tensor:
 
 
 class _Q:
-    """Rounding policy: identity (fp32 oracle) or bf16 round-trip (emulation)."""
+    """Rounding policy: identity (fp32 oracle), bf16 round-trip at every rounding point of the HIP path (`True`), or at a chosen
+    subset of them (a collection of point names: "img", "w", "xn", "qkv", "p", "o", "h" -- tools/parity_attribution.py uses
+    this to measure which rounding point carries the deviation from the fp32 reference)."""
 
-    def __init__(self, emulate: bool):
-        self.emulate = emulate
+    POINTS = ("img", "w", "xn", "qkv", "p", "o", "h")
 
-    def __call__(self, t: Tensor) -> Tensor:
-        return _bf16(t) if self.emulate else t
+    def __init__(self, emulate):
+        self.points = frozenset(self.POINTS) if emulate is True else frozenset(emulate or ())
+        unknown = self.points - frozenset(self.POINTS)
+        if unknown:
+            raise ValueError(f"unknown rounding points {sorted(unknown)}")
+        self.emulate = bool(self.points)
+
+    def on(self, point: str) -> bool:
+        return point in self.points
+
+    def __call__(self, t: Tensor, point: str = None) -> Tensor:
+        if point is None:
+            return _bf16(t) if self.emulate else t
+        return _bf16(t) if point in self.points else t
 
 
 def posemb_sincos_2d(h: int, w: int, dim: int, temperature: float = 10000.0) -> Tensor:

@@ -49,11 +49,11 @@ def mha_self_attention(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out
     """
     B, S, E = x.shape
     dh = E // heads
-    qkv = Q(x @ Q(in_w).t() + in_b)
+    qkv = Q(x @ Q(in_w, "w").t() + in_b, "qkv")
     q, k, v = qkv.chunk(3, dim=-1)
     q, k, v = (t.reshape(B, S, heads, dh).permute(0, 2, 1, 3) for t in (q, k, v))
     dots = torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
-    if not Q.emulate:
+    if not Q.on("p"):
         attn = torch.softmax(dots, dim=-1)
         if robust:
             attn = sinkhorn_normalise(attn)
@@ -66,36 +66,36 @@ def mha_self_attention(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out
             o = torch.matmul(_bf16(sinkhorn_normalise(p / l)), v)
         else:
             o = torch.matmul(_bf16(p), v) / l
-    o = Q(o.permute(0, 2, 1, 3).reshape(B, S, E))
-    return o @ Q(out_w).t() + out_b
+    o = Q(o.permute(0, 2, 1, 3).reshape(B, S, E), "o")
+    return o @ Q(out_w, "w").t() + out_b
 
 
 def encoder_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, robust: bool, Q: _Q,
                   eps: float = 1e-6, capture: Optional[dict] = None, tag: str = "") -> Tensor:
     """EncoderBlock.forward, vit.py:118-130 (dropout p=0).  `capture[tag + ".attn_out"]` receives the residual stream
     after the attention half (vit.py:126), for the per-half localisation in tests/test_model_gpu.py."""
-    a = Q(layer_norm(x, sd[pfx + "ln_1.weight"], sd[pfx + "ln_1.bias"], eps))
+    a = Q(layer_norm(x, sd[pfx + "ln_1.weight"], sd[pfx + "ln_1.bias"], eps), "xn")
     a = mha_self_attention(a, sd[pfx + "self_attention.in_proj_weight"], sd[pfx + "self_attention.in_proj_bias"],
                            sd[pfx + "self_attention.out_proj.weight"], sd[pfx + "self_attention.out_proj.bias"],
                            heads, robust, Q)
     x = a + x
     if capture is not None:
         capture[tag + ".attn_out"] = x.detach().clone()
-    y = Q(layer_norm(x, sd[pfx + "ln_2.weight"], sd[pfx + "ln_2.bias"], eps))
-    u = y @ Q(sd[pfx + "mlp.0.weight"]).t() + sd[pfx + "mlp.0.bias"]
-    h = Q(gelu_erf(u))
-    y = h @ Q(sd[pfx + "mlp.3.weight"]).t() + sd[pfx + "mlp.3.bias"]
+    y = Q(layer_norm(x, sd[pfx + "ln_2.weight"], sd[pfx + "ln_2.bias"], eps), "xn")
+    u = y @ Q(sd[pfx + "mlp.0.weight"], "w").t() + sd[pfx + "mlp.0.bias"]
+    h = Q(gelu_erf(u), "h")
+    y = h @ Q(sd[pfx + "mlp.3.weight"], "w").t() + sd[pfx + "mlp.3.bias"]
     return x + y
 
 
 def vit_forward(sd: Dict[str, Tensor], img: Tensor, *, patch_size: int, num_heads: int,
-                robust: bool = False, emulate_bf16: bool = False, eps: float = 1e-6,
+                robust: bool = False, emulate_bf16=False, eps: float = 1e-6,
                 capture: Optional[dict] = None) -> Tensor:
     """VisionTransformer.forward, vit.py:335-351."""
     Q = _Q(emulate_bf16)
     w = sd["conv_proj.weight"]
     D = w.shape[0]
-    x = patchify_cp1p2(Q(img), patch_size) @ Q(w.reshape(D, -1)).t() + sd["conv_proj.bias"]
+    x = patchify_cp1p2(Q(img, "img"), patch_size) @ Q(w.reshape(D, -1), "w").t() + sd["conv_proj.bias"]
     B = x.shape[0]
     x = torch.cat([sd["class_token"].expand(B, -1, -1), x], dim=1)
     x = x + sd["encoder.pos_embedding"]

@@ -22,8 +22,8 @@ for STEP in "$@"; do
       timeout -k 10 400 python bench.py --arch $A $A2 > $OUT/bench_$A${A3:+_$A3}.json 2> $OUT/bench_$A${A3:+_$A3}.err; RC=$?
       head -c 600 $OUT/bench_$A${A3:+_$A3}.json; echo; tail -12 $OUT/bench_$A${A3:+_$A3}.err ;;
     graphnodes)
-      timeout -k 10 300 python tools/graph_nodes.py $A1 $OUT/graph_$A1.dot > $OUT/graphnodes_$A1.log 2>&1; RC=$?
-      tail -60 $OUT/graphnodes_$A1.log; rm -f $OUT/graph_$A1.dot.keep ;;
+      timeout -k 10 300 python tools/graph_nodes.py $A1 > $OUT/graphnodes_$A1.log 2>&1; RC=$?
+      tail -70 $OUT/graphnodes_$A1.log ;;
     gemmab)
       only=$A2 timeout -k 10 500 python tools/gemm_bench.py $A1 5 > $OUT/gemmab.log 2>&1; RC=$?; cat $OUT/gemmab.log ;;
     stepab)
