@@ -15,7 +15,8 @@
  *     in ELEMENTS.  "stream" tensors (the residual stream) are fp32 or bf16, selected by dtype.
  *   - Return value: 0 = ok; < 0 = argument/shape error detected on the host before any launch
  *     (NRV_ERR_*); > 0 = hipError_t from the launch.  No exceptions cross the ABI.
- *   - Stateless and re-entrant; no globals except read-only kernel handles.
+ *   - Re-entrant; no mutable globals except ONE process-wide planning knob, nrv_set_reserved_cus() (below): it changes
+ *     the tile / split plans of every later GEMM launch of the process, whichever thread or stream issues it.
  *   - Built for gfx950 only (wave64, MFMA 16x16x32 bf16, buffer_load...lds, ds_read_b64_tr_b16).
  */
 #ifndef NRV_H_
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 10
+#define NRV_ABI_VERSION 11
 
 /* dtype codes */
 #define NRV_F32 0
@@ -136,7 +137,9 @@ int nrv_colsum_bf16(const void* X, int64_t ld, float* out, int64_t T, int64_t N,
  *   qkv bf16 [B, N, 3*H*dh] exactly as the QKV projection writes it (feature index =
  *   which*(H*dh) + h*dh + d, simple_vit.py:67-68); out bf16 [B, N, H*dh] ('b h n d -> b n (h d)');
  *   lse fp32 [B, H, N] = log(sum_j exp(scale * q.k_j)) saved for the backward.
- *   dh == 64, 1 <= N <= 256.  The [N,N] score matrix never leaves the CU.
+ *   Shapes: dh == 64 and 1 <= N <= 256 run the single-pass kernels (the [N,N] score matrix never leaves the CU);
+ *   any other N with dh in {32, 64, 80, 96, 128} runs the streaming kernels (online softmax over 64-key tiles:
+ *   vit_h_14, 384-px checkpoints, SimpleViT(dim_head=...)); everything else returns NRV_ERR_SHAPE.
  * ---------------------------------------------------------------------------------------- */
 int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
                  int B, int N, int H, int dh, float scale, void* stream);
@@ -208,12 +211,14 @@ int nrv_cast_transpose_batched(const nrv_cast_job* jobs_dev, int njobs, int64_t 
 int nrv_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
 
 /* Row gather / scatter-add of the residual stream (MAE token selection, mae.py:75-76 and its backward):
- *   fwd: out[r, :] = src[index[r], :]   (rows_out rows, dim % 4 == 0, fp32)
- *   bwd: dsrc[index[r], :] += dout[r, :] (indices unique per call => plain stores into a zeroed dsrc) */
+ *   fwd: out[r, :] = src[index[r], :]   (rows_out rows, dim % 4 == 0, fp32; src has rows_src rows)
+ *   bwd: dsrc[index[r], :] += dout[r, :] (indices unique per call => plain stores into a zeroed dsrc of rows_src rows)
+ *   index is DEVICE data: an entry outside [0, rows_src) never becomes an address -- the gather writes a zero row for it,
+ *   the scatter drops it (ABI 11: the bound is part of the call, a wrong index cannot fault the GPU). */
 int nrv_gather_rows_f32(const float* src, const int64_t* index, float* out,
-                        int64_t rows_out, int dim, void* stream);
+                        int64_t rows_out, int64_t rows_src, int dim, void* stream);
 int nrv_scatter_rows_f32(const float* dout, const int64_t* index, float* dsrc,
-                         int64_t rows_out, int dim, void* stream);
+                         int64_t rows_out, int64_t rows_src, int dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer step on flat fp32 buffers (replaces torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of the reference

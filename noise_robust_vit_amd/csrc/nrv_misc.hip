@@ -146,16 +146,21 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
     }
 }
 
-// rows of the fp32 residual stream: gather out[r] = src[index[r]]; scatter dsrc[index[r]] = dout[r]
+// rows of the fp32 residual stream: gather out[r] = src[index[r]]; scatter dsrc[index[r]] = dout[r].  The indices are device data
+// (a permutation computed by the caller's kernels): an index outside [0, rows_src) can never become an address -- the gather
+// writes a zero row for it, the scatter drops the row (ABI 11; the host cannot validate device data without a sync).
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void move_rows_kernel(const float* __restrict__ a, const long long* __restrict__ index,
-                                                        float* __restrict__ o, long long rows, int dim) {
+                                                        float* __restrict__ o, long long rows, long long rows_src, int dim) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
         const long long s = index[r];
-        const float* src = SCATTER ? a + r * dim : a + s * dim;
+        const bool ok = s >= 0 && s < rows_src;                  // wave-uniform
+        if (SCATTER && !ok) continue;
+        const float* src = SCATTER ? a + r * dim : a + (ok ? s : 0) * dim;
         float* dst = SCATTER ? o + s * dim : o + r * dim;
-        for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<f32x4_t*>(dst + c) = *reinterpret_cast<const f32x4_t*>(src + c);
+        for (int c = lane * 4; c < dim; c += 256)
+            *reinterpret_cast<f32x4_t*>(dst + c) = ok ? *reinterpret_cast<const f32x4_t*>(src + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -273,25 +278,25 @@ extern "C" int nrv_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* 
 }
 
 extern "C" int nrv_gather_rows_f32(const float* src, const int64_t* index, float* out,
-                                   int64_t rows_out, int dim, void* stream) {
+                                   int64_t rows_out, int64_t rows_src, int dim, void* stream) {
     if (!src || !index || !out) return NRV_ERR_NULL;
-    if (rows_out <= 0 || dim <= 0 || (dim & 3)) return NRV_ERR_SHAPE;
+    if (rows_out <= 0 || rows_src <= 0 || dim <= 0 || (dim & 3)) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(src) || !nrv_aligned16(out)) return NRV_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL((move_rows_kernel<false>), dim3(grid_for(rows_out, 4)), dim3(256), 0, s,
-                       src, reinterpret_cast<const long long*>(index), out, (long long)rows_out, dim);
+                       src, reinterpret_cast<const long long*>(index), out, (long long)rows_out, (long long)rows_src, dim);
     NRV_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int nrv_scatter_rows_f32(const float* dout, const int64_t* index, float* dsrc,
-                                    int64_t rows_out, int dim, void* stream) {
+                                    int64_t rows_out, int64_t rows_src, int dim, void* stream) {
     if (!dout || !index || !dsrc) return NRV_ERR_NULL;
-    if (rows_out <= 0 || dim <= 0 || (dim & 3)) return NRV_ERR_SHAPE;
+    if (rows_out <= 0 || rows_src <= 0 || dim <= 0 || (dim & 3)) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(dout) || !nrv_aligned16(dsrc)) return NRV_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL((move_rows_kernel<true>), dim3(grid_for(rows_out, 4)), dim3(256), 0, s,
-                       dout, reinterpret_cast<const long long*>(index), dsrc, (long long)rows_out, dim);
+                       dout, reinterpret_cast<const long long*>(index), dsrc, (long long)rows_out, (long long)rows_src, dim);
     NRV_CHECK_LAUNCH();
     return 0;
 }

@@ -373,7 +373,9 @@ def gather_rows(src: Tensor, index: Tensor) -> Tensor:
     _f32(src, "src"); _dev(index, "index")
     src = src.contiguous(); index = index.contiguous()
     out = torch.empty(index.numel(), src.shape[1], dtype=torch.float32, device=src.device)
-    check(_lib.load().nrv_gather_rows_f32(src.data_ptr(), index.data_ptr(), out.data_ptr(), index.numel(), src.shape[1], _stream()),
+    if index.dtype != torch.int64:
+        raise NrvError(f"gather_rows: index must be int64, got {index.dtype}")
+    check(_lib.load().nrv_gather_rows_f32(src.data_ptr(), index.data_ptr(), out.data_ptr(), index.numel(), src.shape[0], src.shape[1], _stream()),
           "nrv_gather_rows_f32")
     return out
 
@@ -383,7 +385,9 @@ def scatter_rows(dout: Tensor, index: Tensor, rows_src: int) -> Tensor:
     _f32(dout, "dout"); _dev(index, "index")
     dout = dout.contiguous(); index = index.contiguous()
     dsrc = torch.zeros(rows_src, dout.shape[1], dtype=torch.float32, device=dout.device)
-    check(_lib.load().nrv_scatter_rows_f32(dout.data_ptr(), index.data_ptr(), dsrc.data_ptr(), index.numel(), dout.shape[1], _stream()),
+    if index.dtype != torch.int64 or index.numel() != dout.shape[0]:
+        raise NrvError("scatter_rows: index must be int64 with one entry per row of dout")
+    check(_lib.load().nrv_scatter_rows_f32(dout.data_ptr(), index.data_ptr(), dsrc.data_ptr(), index.numel(), rows_src, dout.shape[1], _stream()),
           "nrv_scatter_rows_f32")
     return dsrc
 

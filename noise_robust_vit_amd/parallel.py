@@ -44,23 +44,29 @@ def make_process_group(rank: int, world: int, device=None, backend: str = "nccl"
     opts = None
     desc = f"{backend} default communicator config"
     if backend == "nccl" and (max_ctas or min_ctas or high_priority_stream):
-        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=bool(high_priority_stream))
-        if max_ctas:
-            opts.config.max_ctas = int(max_ctas)
-        if min_ctas:
-            opts.config.min_ctas = int(min_ctas)
-        desc = f"rccl max_ctas={max_ctas or 'default'} min_ctas={min_ctas or 'default'} high_priority_stream={bool(high_priority_stream)}"
+        # the fallback is decided BEFORE the rendezvous, from what this torch / RCCL build exposes: errors of
+        # init_process_group itself (rendezvous timeout, port in use, device binding) propagate unchanged
+        why = None
+        if not hasattr(dist, "ProcessGroupNCCL") or not hasattr(dist.ProcessGroupNCCL, "Options"):
+            why = "torch.distributed has no ProcessGroupNCCL.Options"
+        else:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=bool(high_priority_stream))
+            cfg = getattr(opts, "config", None)
+            if (max_ctas or min_ctas) and (cfg is None or not hasattr(cfg, "max_ctas") or not hasattr(cfg, "min_ctas")):
+                why, opts = "ProcessGroupNCCL.Options has no config.max_ctas / min_ctas", None
+        if opts is not None:
+            if max_ctas:
+                opts.config.max_ctas = int(max_ctas)
+            if min_ctas:
+                opts.config.min_ctas = int(min_ctas)
+            desc = f"rccl max_ctas={max_ctas or 'default'} min_ctas={min_ctas or 'default'} high_priority_stream={bool(high_priority_stream)}"
+        else:
+            desc = f"{backend} default communicator config (requested max_ctas={max_ctas} min_ctas={min_ctas} not applied: {why})"
     args = dict(rank=rank, world_size=world, **kw)
     if device is not None and backend == "nccl":
         args["device_id"] = device
     if opts is not None:
-        try:
-            dist.init_process_group(backend, pg_options=opts, **args)
-            return desc
-        except (RuntimeError, TypeError, ValueError) as e:       # a build of RCCL / torch without these config fields
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            desc = f"{backend} default communicator config (the requested one was refused: {type(e).__name__})"
+        args["pg_options"] = opts
     dist.init_process_group(backend, **args)
     return desc
 
@@ -256,16 +262,37 @@ class GradReducer:
 
     # ---- step protocol -----------------------------------------------------------------------
     def begin_step(self) -> None:
+        if self._reserved:                      # a backward that raised after the first bucket never reached finish_step: the
+            from . import kernels as K          # process-wide CU reservation must not outlive its step
+            K.set_reserved_cus(0)
+            self._reserved = False
         self._ready = set()
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._stage_slabs = []
-        # autograd accumulates (+=) into existing .grad views: clear the ones it manages
+        # autograd accumulates (+=) into existing .grad views: clear the ones it manages -- as the few contiguous ranges they
+        # form in the flat buffer (head ... | ... positions, class token), not one fill kernel per parameter
+        for v in self._autograd_ranges():
+            v.zero_()
         for p in self._params:
-            if id(p) not in self._sink_managed:
-                self._views[id(p)].zero_()
-                if p.grad is not self._views[id(p)]:
-                    p.grad = self._views[id(p)]
+            if id(p) not in self._sink_managed and p.grad is not self._views[id(p)]:
+                p.grad = self._views[id(p)]
+
+    def _autograd_ranges(self) -> List[torch.Tensor]:
+        """Views over the maximal runs of slots whose gradients autograd accumulates (recomputed when the set of kernel-written
+        parameters grew: it is only known after the first backward)."""
+        key = len(self._sink_managed)
+        if getattr(self, "_zr_key", None) != key:
+            spans = sorted((o, o + (n + 3) // 4 * 4) for pid, (o, n) in self._slot.items() if pid not in self._sink_managed)
+            runs: List[List[int]] = []
+            for a, b in spans:
+                if runs and runs[-1][1] == a:
+                    runs[-1][1] = b
+                else:
+                    runs.append([a, b])
+            self._zr = [self.flat[a:b] for a, b in runs]
+            self._zr_key = key
+        return self._zr
 
     def finish_step(self) -> None:
         # Parameters that received no gradient on THIS rank this step.  Their slots must not carry anything into the

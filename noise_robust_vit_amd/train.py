@@ -199,6 +199,11 @@ class Trainer:
 
     def _replay(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         c = self.cfg
+        if x.shape != self._gx.shape or y.shape != self._gy.shape:
+            # a short last batch (or a batch-1 probe, which copy_ would silently broadcast): the graph holds the captured shapes only
+            loss = self.forward_backward(x, y)
+            self.optimizer_step()
+            return loss
         if x.data_ptr() != self._gx.data_ptr():
             self._gx.copy_(x, non_blocking=True)
         if y.data_ptr() != self._gy.data_ptr():
@@ -207,7 +212,7 @@ class Trainer:
         self.opt.stage_step_scalars(lr)
         self._graph.replay()
         self.step_idx += 1
-        return self._gloss
+        return self._gloss.clone()              # the static tensor is overwritten by the next replay: callers may keep losses
 
     @torch.no_grad()
     def eval_step(self, x: torch.Tensor, y: torch.Tensor, process_group=None) -> torch.Tensor:

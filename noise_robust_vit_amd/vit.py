@@ -300,4 +300,4 @@ def vit_l_32(**kwargs: Any) -> VisionTransformer:
 
 
 def vit_h_14(**kwargs: Any) -> VisionTransformer:
-    return _vision_transformer(14, 32, 16, 1280, 5120, **kwargs)      # head_dim 80: refused by the attention kernel
+    return _vision_transformer(14, 32, 16, 1280, 5120, **kwargs)      # head_dim 80, 257 tokens: the streaming attention kernels (csrc/nrv_attn_gen.hip)

@@ -232,3 +232,38 @@ def test_grad_reducer_places_grouped_parameters_back_to_back():
     for (o0, n0), (o1, _) in zip(spans, spans[1:]):
         assert o0 + (n0 + 3) // 4 * 4 == o1
     assert spans[-1][0] + (spans[-1][1] + 3) // 4 * 4 == red.flat.numel()
+
+
+def test_begin_step_releases_a_cu_reservation_left_by_an_aborted_backward(monkeypatch):
+    """the CU reservation is process-wide; a backward that raises after the first bucket never reaches finish_step,
+    so the next begin_step must put the GEMM planning back to all CUs."""
+    from noise_robust_vit_amd import kernels as K
+    from noise_robust_vit_amd.parallel import GradReducer
+    calls = []
+    monkeypatch.setattr(K, "set_reserved_cus", lambda n: calls.append(n) or 0)
+    red = GradReducer(torch.nn.Linear(4, 3), 1)
+    red._reserved = True                      # what _launch leaves behind when the step never finishes
+    red.begin_step()
+    assert calls == [0] and red._reserved is False
+    red.begin_step()
+    assert calls == [0]                       # nothing to release: no second call
+
+
+def test_begin_step_clears_autograd_slots_as_contiguous_ranges():
+    """The autograd-managed gradient slots are zeroed as maximal runs of the flat buffer (not one fill per
+    parameter), and the runs follow the set of kernel-written parameters."""
+    from noise_robust_vit_amd.parallel import GradReducer
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+    red = GradReducer(net, 1)
+    assert len(red._autograd_ranges()) == 1 and red._autograd_ranges()[0].numel() == red.flat.numel()
+    red.flat.fill_(3.0)
+    w_mid = net[1].weight
+    red.target(w_mid)                         # a kernel writes this one: its slot is not cleared by begin_step
+    red.begin_step()
+    o, n = red.slot(w_mid)
+    assert len(red._autograd_ranges()) == 2
+    assert torch.all(red.flat[o:o + n] == 3.0)
+    mask = torch.ones_like(red.flat, dtype=torch.bool)
+    mask[o:o + n] = False
+    assert torch.all(red.flat[mask] == 0.0)
+    assert all(p.grad is red._views[id(p)] for p in net.parameters())

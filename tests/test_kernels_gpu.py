@@ -551,6 +551,24 @@ def test_gather_scatter_rows(dev):
     assert torch.equal(s, ref)
 
 
+def test_gather_scatter_rows_out_of_range_index_cannot_become_an_address(dev):
+    """ABI 11: the source-row count is part of the call; an index outside [0, rows_src) (device data the host cannot check without
+    a sync) gathers a zero row / is dropped by the scatter instead of reading or writing through it."""
+    k = _k()
+    src = rnd((40, 192), dev, 91, 1.0, torch.float32)
+    idx = torch.tensor([3, 40, -1, 7, 2 ** 40, 39], device=dev, dtype=torch.int64)
+    ok = torch.tensor([True, False, False, True, False, True], device=dev)
+    g = k.gather_rows(src, idx)
+    ref = torch.zeros(6, 192, device=dev)
+    ref[ok] = src[idx[ok]]
+    assert torch.equal(g, ref)
+    d = rnd((6, 192), dev, 92, 1.0, torch.float32)
+    s = k.scatter_rows(d, idx, 40)
+    ref = torch.zeros_like(src)
+    ref[idx[ok]] = d[ok]
+    assert torch.equal(s, ref)
+
+
 # ------------------------------------------------------------------ error behaviour (no silent fallbacks)
 def test_errors_are_loud(dev):
     k = _k()

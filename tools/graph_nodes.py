@@ -33,6 +33,12 @@ trainer._graph = None                   # never replayed here
 torch.cuda.synchronize()
 
 hip = C.CDLL("libamdhip64.so")
+hip.hipGraphGetNodes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+hip.hipGraphNodeGetType.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+hip.hipGraphKernelNodeGetParams.argtypes = [C.c_void_p, C.c_void_p]
+hip.hipGraphMemcpyNodeGetParams.argtypes = [C.c_void_p, C.c_void_p]
+hip.hipGraphMemsetNodeGetParams.argtypes = [C.c_void_p, C.c_void_p]
+hip.hipPointerGetAttributes.argtypes = [C.c_void_p, C.c_void_p]
 hgraph = C.c_void_p(graph.raw_cuda_graph())
 n = C.c_size_t(0)
 assert hip.hipGraphGetNodes(hgraph, None, C.byref(n)) == 0
@@ -93,7 +99,9 @@ KINDS = {0: "H2H", 1: "H2D", 2: "D2H", 3: "D2D", 4: "default"}
 print(f"{arch}: {n.value} nodes")
 for i in range(n.value):
     t = C.c_int(-1)
-    hip.hipGraphNodeGetType(nodes[i], C.byref(t))
+    rc_t = hip.hipGraphNodeGetType(nodes[i], C.byref(t))
+    if rc_t != 0 and i == 0:
+        print('hipGraphNodeGetType rc', rc_t)
     name = TYPES[t.value] if 0 <= t.value < len(TYPES) else str(t.value)
     kinds[name] += 1
     if name == "kernel":
