@@ -140,20 +140,26 @@ int nrv_colsum_bf16(const void* X, int64_t ld, float* out, int64_t T, int64_t N,
  *   Shapes: dh == 64 and 1 <= N <= 256 run the single-pass kernels (the [N,N] score matrix never leaves the CU);
  *   any other N with dh in {32, 64, 80, 96, 128} runs the streaming kernels (online softmax over 64-key tiles:
  *   vit_h_14, 384-px checkpoints, SimpleViT(dim_head=...)); everything else returns NRV_ERR_SHAPE.
- * ---------------------------------------------------------------------------------------- */
+ *   layout (ABI 11): 0 = the row-major tensors above.  NRV_ATTN_QKV_BLOCKED: qkv (and dqkv) as [3*H][B*N][dh] -- the 3 H
+ *   column blocks of dh features of the projection's [B*N, 3*H*dh] output each stored as their own contiguous [B*N, dh]
+ *   matrix, so that the q / k / v slice of one (batch, head) is ONE contiguous N*dh*2 bytes instead of N segments of dh*2
+ *   bytes at a 3*H*dh*2-byte stride.  NRV_ATTN_OUT_BLOCKED: out (and dout) as [H][B*N][dh] likewise.  The blocked forms are
+ *   what nrv_gemm_nt_bf16 writes with c_block / reads with a_block; single-pass shapes (dh 64, N <= 256) only. */
+#define NRV_ATTN_QKV_BLOCKED 1
+#define NRV_ATTN_OUT_BLOCKED 2
 int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
-                 int B, int N, int H, int dh, float scale, void* stream);
+                 int B, int N, int H, int dh, float scale, int layout, void* stream);
 
 /* Backward: dqkv bf16 [B, N, 3*H*dh] from dout bf16 [B, N, H*dh]; recomputes P from q,k and lse.
  *   delta_ws: fp32 [B*H*N] scratch (row sums of dout*out). */
 int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse,
                  void* dqkv_bf16, float* delta_ws,
-                 int B, int N, int H, int dh, float scale, void* stream);
+                 int B, int N, int H, int dh, float scale, int layout, void* stream);
 
 /* Introspection only (Recorder-style attention maps, recorder.py:24-31; never on the training path):
  *   probs fp32 [B, H, N, N] = exp(scale * q.k - lse), i.e. the softmax the fused kernels keep on chip. */
 int nrv_attn_probs(const void* qkv_bf16, const float* lse, float* probs,
-                   int B, int N, int H, int dh, float scale, void* stream);
+                   int B, int N, int H, int dh, float scale, int layout, void* stream);
 
 /* "robust" attention (robust=True): softmax followed by Sinkhorn normalisation -- 3 x (row /, column /) and a final
  * row / -- utils.py:1025-1037, wired at simple_vit.py:56-57.  Same layouts as nrv_attn_fwd.

@@ -19,6 +19,7 @@ NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
 ABI_VERSION = 11
+ATTN_QKV_BLOCKED, ATTN_OUT_BLOCKED = 1, 2      # include/nrv.h: NRV_ATTN_*_BLOCKED
 
 # name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -40,10 +41,10 @@ SIGNATURES = {
                                  c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "nrv_colsum_workspace": (c_size_t, [c_int64, c_int64]),
     "nrv_colsum_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
-    "nrv_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "nrv_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "nrv_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "nrv_attn_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                             c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "nrv_attn_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "nrv_attn_sinkhorn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "nrv_attn_sinkhorn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_int, c_int, c_float, c_void_p]),

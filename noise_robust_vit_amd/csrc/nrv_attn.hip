@@ -35,16 +35,28 @@ namespace {
 
 using namespace nrv_attn;
 struct AttnParams {
-    const bf16_t* qkv;     // [B, N, 3*H*64]
-    const bf16_t* out;     // [B, N, H*64]      (bwd)
-    const bf16_t* dout;    // [B, N, H*64]      (bwd)
-    bf16_t* o;             // fwd output
-    bf16_t* dqkv;          // bwd output
+    const bf16_t* qkv;     // q / k / v of (b, h), token t, feature d at  which * q_ws + h * q_hs + b * q_bs + t * q_rs + d  (elements)
+    const bf16_t* out;     // (bwd) o / dO of (b, h), token t at  h * o_hs + b * o_bs + t * o_rs + d
+    const bf16_t* dout;    // (bwd)
+    bf16_t* o;             // fwd output, the o layout
+    bf16_t* dqkv;          // bwd output, the qkv layout
     float* lse;            // [B, H, N]
     float* delta;          // [B, H, N]
     int B, N, H;
     float scale;
+    // NRV_LAYOUT_ROWMAJOR: qkv [B*N, 3*H*64] (q_rs = 3 H 64, q_ws = H 64, q_hs = 64, q_bs = N q_rs), o [B*N, H*64]
+    // NRV_LAYOUT_BLOCKED : qkv [3*H][B*N][64]  (q_rs = 64, q_ws = H B N 64, q_hs = B N 64, q_bs = N 64), o [H][B*N][64]:
+    //                      every head slice [N x 64] is ONE contiguous 128 N bytes instead of N segments of 128 bytes
+    long long q_rs, q_ws, q_hs, q_bs, o_rs, o_hs, o_bs;
 };
+
+void set_layout(AttnParams& p, int layout, int dh) {
+    const long long T = (long long)p.B * p.N;
+    if (layout & NRV_ATTN_QKV_BLOCKED) { p.q_rs = dh; p.q_ws = (long long)p.H * T * dh; p.q_hs = T * dh; p.q_bs = (long long)p.N * dh; }
+    else { p.q_rs = 3ll * p.H * dh; p.q_ws = (long long)p.H * dh; p.q_hs = dh; p.q_bs = p.N * p.q_rs; }
+    if (layout & NRV_ATTN_OUT_BLOCKED) { p.o_rs = dh; p.o_hs = T * dh; p.o_bs = (long long)p.N * dh; }
+    else { p.o_rs = (long long)p.H * dh; p.o_hs = dh; p.o_bs = p.N * p.o_rs; }
+}
 
 // ---------------------------------------------------------------------------------------------
 // forward, 4 fat waves: one workgroup of 4 waves (one per SIMD, <= 256 VGPRs) per (batch, head), TWO workgroups per CU.
@@ -75,9 +87,9 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_ke
     constexpr int MT = (NT == 13 || NT == 14) ? 1 : 2;   // trailing key tiles that can hold padding rows (launch_fwd_fat rounds other counts up to even)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, H = p.H;
-    const long long ldq = 3ll * H * DH;
+    const long long ldq = p.q_rs;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const bf16_t* hb = p.qkv + (long long)b * N * ldq + h * DH;
+    const bf16_t* hb = p.qkv + (long long)b * p.q_bs + h * p.q_hs;
     const int g = lane >> 4, qc = lane & 15;
     const float sc = p.scale * LOG2E;
     const char* kimg = smem;
@@ -97,16 +109,18 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_ke
     };
     if (wave < npairs) load_q(wave);
     {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(hb, 0x7fffffffull);
+        const __amdgpu_buffer_rsrc_t rk = make_rsrc(hb + p.q_ws, 0x7fffffffull), rv = make_rsrc(hb + 2 * p.q_ws, 0x7fffffffull);
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar: the descriptor select below must stay in SGPRs
 #pragma unroll
         for (int i = 0; i < JPW; ++i) {
-            const int j = wave * JPW + i;
+            const int j = wave_u * JPW + i;
             const bool isv = j >= NP / 8;
             const int r = 8 * (isv ? j - NP / 8 : j) + (lane >> 3);
             const int pos = lane & 7;
             const int c = isv ? ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1)) : (pos ^ ((r >> 1) & 7));
-            const unsigned vo = (r < N) ? (unsigned)(r * ldq * 2 + c * 16 + (isv ? 2 : 1) * H * DH * 2) : NRV_OOB;
-            dma16_nt(rs, smem + j * 1024, vo);
+            const unsigned vo = (r < N) ? (unsigned)(r * ldq * 2 + c * 16) : NRV_OOB;
+            if (isv) dma16_nt(rv, smem + j * 1024, vo);
+            else dma16_nt(rk, smem + j * 1024, vo);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): through the builtin so that hipcc's own counting stays exact
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_ke
                 ov[pr] = u32x4_t{lo[0], hi[0], lo[1], hi[1]};
             }
             if (q < N) {
-                bf16_t* dst = p.o + ((long long)b * N + q) * (H * DH) + h * DH + d_lane;
+                bf16_t* dst = p.o + (long long)b * p.o_bs + h * p.o_hs + (long long)q * p.o_rs + d_lane;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) *reinterpret_cast<u32x4_t*>(dst + 32 * pr) = ov[pr];
                 if (g == 0) p.lse[((long long)b * H + h) * N + q] = (m[t] + __builtin_amdgcn_logf(l[t])) * LN2;
@@ -291,10 +305,10 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, H = p.H;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const long long ldq = 3ll * H * DH, ldo = (long long)H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    const bf16_t* obase = p.out + (long long)b * N * ldo + h * DH;
-    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
+    const long long ldq = p.q_rs, ldo = p.o_rs;
+    const bf16_t* qbase = p.qkv + (long long)b * p.q_bs + h * p.q_hs;
+    const bf16_t* obase = p.out + (long long)b * p.o_bs + h * p.o_hs;
+    const bf16_t* dobase = p.dout + (long long)b * p.o_bs + h * p.o_hs;
     const int g = lane >> 4, qc = lane & 15;
     const float sc = p.scale * LOG2E;
     const int npairs = (N + 31) >> 5;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat
         }
     };
     if (wave < npairs) load_rows(wave);
-    dma_two_images<NT>(smem, qbase + H * DH, ldq, qbase + 2 * H * DH, ldq, N, wave, lane);
+    dma_two_images<NT>(smem, qbase + p.q_ws, ldq, qbase + 2 * p.q_ws, ldq, N, wave, lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" ::: "memory");
     __syncthreads();
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int q = q0 + t * 16;
-            store_tile_bf16(p.dqkv + ((long long)b * N + (q < N ? q : 0)) * ldq + h * DH, keep[t], p.scale, g, q < N);
+            store_tile_bf16(p.dqkv + (long long)b * p.q_bs + h * p.q_hs + (long long)(q < N ? q : 0) * ldq, keep[t], p.scale, g, q < N);
         }
     }
 }
@@ -418,9 +432,9 @@ __global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, H = p.H;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const long long ldq = 3ll * H * DH, ldo = (long long)H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
+    const long long ldq = p.q_rs, ldo = p.o_rs;
+    const bf16_t* qbase = p.qkv + (long long)b * p.q_bs + h * p.q_hs;
+    const bf16_t* dobase = p.dout + (long long)b * p.o_bs + h * p.o_hs;
     const int g = lane >> 4, kc = lane & 15;
     const float sc = p.scale * LOG2E;
     const int npairs = (N + 31) >> 5;
@@ -433,8 +447,8 @@ __global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const 
             const int kr = key < N ? key : N - 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                kf[t][ks] = load_frag_global(qbase + H * DH + (long long)kr * ldq + ks * 32 + g * 8);
-                vf[t][ks] = load_frag_global(qbase + 2 * H * DH + (long long)kr * ldq + ks * 32 + g * 8);
+                kf[t][ks] = load_frag_global(qbase + p.q_ws + (long long)kr * ldq + ks * 32 + g * 8);
+                vf[t][ks] = load_frag_global(qbase + 2 * p.q_ws + (long long)kr * ldq + ks * 32 + g * 8);
             }
         }
     };
@@ -530,9 +544,9 @@ __global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = k0 + t * 16;
-            bf16_t* row = p.dqkv + ((long long)b * N + (key < N ? key : 0)) * ldq + h * DH;
-            store_tile_bf16(row + H * DH, dk[t], p.scale, g, key < N);
-            store_tile_bf16(row + 2 * H * DH, dv[t], 1.0f, g, key < N);
+            bf16_t* row = p.dqkv + (long long)b * p.q_bs + h * p.q_hs + (long long)(key < N ? key : 0) * ldq;
+            store_tile_bf16(row + p.q_ws, dk[t], p.scale, g, key < N);
+            store_tile_bf16(row + 2 * p.q_ws, dv[t], 1.0f, g, key < N);
         }
     }
 }
@@ -597,13 +611,16 @@ int launch_bwd_fat(const AttnParams& p, hipStream_t s) {
 // in fp32.  NOT on the training path (which never materialises P): a plain VALU kernel, 16 queries per workgroup, the 16
 // query rows in LDS as fp32, one (query, key) dot product of 64 per thread and step.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
-                                                         float* __restrict__ probs, int B, int N, int H, float scale) {
+__global__ __launch_bounds__(256) void attn_probs_kernel(const AttnParams p, float* __restrict__ probs) {
     __shared__ float qs[16][DH + 1];
+    const bf16_t* __restrict__ qkv = p.qkv;
+    const float* __restrict__ lse = p.lse;
+    const int N = p.N, H = p.H;
+    const float scale = p.scale;
     const int bh = blockIdx.x, q0 = blockIdx.y * 16;
     const int b = bh / H, h = bh - b * H;
-    const long long ldq = 3ll * H * DH;
-    const bf16_t* base = qkv + (long long)b * N * ldq + h * DH;
+    const long long ldq = p.q_rs;
+    const bf16_t* base = qkv + (long long)b * p.q_bs + h * p.q_hs;
     for (int i = threadIdx.x; i < 16 * DH; i += 256) {
         const int r = i / DH, d = i - r * DH;
         qs[r][d] = (q0 + r < N) ? bf16_to_f32(base[(long long)(q0 + r) * ldq + d]) : 0.f;
@@ -613,7 +630,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
     const int q = q0 + qi;
     const float l = q < N ? lse[((long long)b * H + h) * N + q] : 0.f;
     for (int key = threadIdx.x >> 4; key < N; key += 16) {
-        const bf16_t* kp = base + H * DH + (long long)key * ldq;
+        const bf16_t* kp = base + p.q_ws + (long long)key * ldq;
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < DH / 8; ++c) {
@@ -635,11 +652,19 @@ int shape_class(int B, int N, int H, int dh) {
 
 }  // namespace
 
+// layouts the single-pass kernels address through strides; the streaming kernels take the row-major form only
+static bool layout_ok(int layout, int cls, int B, int N, int H, int dh) {
+    if (layout & ~(NRV_ATTN_QKV_BLOCKED | NRV_ATTN_OUT_BLOCKED)) return false;
+    if (layout != 0 && cls != 1) return false;
+    // byte offsets of the k / v slices from the head's base stay below the 2 GiB window of a buffer descriptor
+    return 2ll * 3 * H * (long long)B * N * dh < 0x7fffffffll;
+}
+
 extern "C" int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
-                            int B, int N, int H, int dh, float scale, void* stream) {
+                            int B, int N, int H, int dh, float scale, int layout, void* stream) {
     if (!qkv_bf16 || !out_bf16 || !lse) return NRV_ERR_NULL;
     const int cls = shape_class(B, N, H, dh);
-    if (cls == 0) return NRV_ERR_SHAPE;
+    if (cls == 0 || !layout_ok(layout, cls, B, N, H, dh)) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(qkv_bf16) || !nrv_aligned16(out_bf16)) return NRV_ERR_ALIGN;
     if (cls == 2) return nrv_attn_gen_fwd(qkv_bf16, out_bf16, lse, B, N, H, dh, scale, static_cast<hipStream_t>(stream));
     AttnParams p{};
@@ -647,16 +672,17 @@ extern "C" int nrv_attn_fwd(const void* qkv_bf16, void* out_bf16, float* lse,
     p.o = static_cast<bf16_t*>(out_bf16);
     p.lse = lse;
     p.B = B; p.N = N; p.H = H; p.scale = scale;
+    set_layout(p, layout, dh);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return launch_fwd_fat(p, s);
 }
 
 extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse,
                             void* dqkv_bf16, float* delta_ws,
-                            int B, int N, int H, int dh, float scale, void* stream) {
+                            int B, int N, int H, int dh, float scale, int layout, void* stream) {
     if (!qkv_bf16 || !out_bf16 || !dout_bf16 || !lse || !dqkv_bf16 || !delta_ws) return NRV_ERR_NULL;
     const int cls = shape_class(B, N, H, dh);
-    if (cls == 0) return NRV_ERR_SHAPE;
+    if (cls == 0 || !layout_ok(layout, cls, B, N, H, dh)) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(qkv_bf16) || !nrv_aligned16(out_bf16) || !nrv_aligned16(dout_bf16) || !nrv_aligned16(dqkv_bf16))
         return NRV_ERR_ALIGN;
     if (cls == 2)
@@ -669,20 +695,25 @@ extern "C" int nrv_attn_bwd(const void* qkv_bf16, const void* out_bf16, const vo
     p.lse = const_cast<float*>(lse);
     p.delta = delta_ws;
     p.B = B; p.N = N; p.H = H; p.scale = scale;
+    set_layout(p, layout, dh);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return launch_bwd_fat(p, s);
 }
 
 extern "C" int nrv_attn_probs(const void* qkv_bf16, const float* lse, float* probs,
-                              int B, int N, int H, int dh, float scale, void* stream) {
+                              int B, int N, int H, int dh, float scale, int layout, void* stream) {
     if (!qkv_bf16 || !lse || !probs) return NRV_ERR_NULL;
     const int cls = shape_class(B, N, H, dh);
-    if (cls == 0) return NRV_ERR_SHAPE;
+    if (cls == 0 || !layout_ok(layout, cls, B, N, H, dh)) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(qkv_bf16)) return NRV_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cls == 2) return nrv_attn_gen_probs(qkv_bf16, lse, probs, B, N, H, dh, scale, s);
-    hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)(B * H), (unsigned)((N + 15) / 16)), dim3(256), 0, s,
-                       static_cast<const bf16_t*>(qkv_bf16), lse, probs, B, N, H, scale);
+    AttnParams p{};
+    p.qkv = static_cast<const bf16_t*>(qkv_bf16);
+    p.lse = const_cast<float*>(lse);
+    p.B = B; p.N = N; p.H = H; p.scale = scale;
+    set_layout(p, layout, dh);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)(B * H), (unsigned)((N + 15) / 16)), dim3(256), 0, s, p, probs);
     NRV_CHECK_LAUNCH();
     return 0;
 }

@@ -259,21 +259,24 @@ def colsum(X: Tensor, *, out: Optional[Tensor] = None, beta: float = 0.0) -> Ten
     return out
 
 
-def attn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
-    """qkv bf16 [B*N, 3*H*dh] -> (out bf16 [B*N, H*dh], lse fp32 [B,H,N]).  simple_vit.py:68-75."""
+def attn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float, layout: int = 0):
+    """qkv bf16 [B*N, 3*H*dh] -> (out bf16 [B*N, H*dh], lse fp32 [B,H,N]).  simple_vit.py:68-75.
+    `layout` (include/nrv.h NRV_ATTN_*_BLOCKED): qkv given as [3*H, B*N, dh] / out returned as [H, B*N, dh]."""
     _bf16(qkv, "qkv")
     if not qkv.is_contiguous() or qkv.numel() != B * N * 3 * H * dh:
-        raise NrvError("attn_fwd: qkv must be contiguous [B*N, 3*H*dh]")
-    out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
+        raise NrvError("attn_fwd: qkv must be contiguous [B*N, 3*H*dh] (or [3*H, B*N, dh] with the blocked layout)")
+    out = (torch.empty(H, B * N, dh, dtype=torch.bfloat16, device=qkv.device) if layout & _lib.ATTN_OUT_BLOCKED
+           else torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device))
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     lib = _lib.load()
     _run("attn_fwd", 4.0 * B * H * N * N * dh, 2 * B * N * H * dh * 4,
-         lambda: lib.nrv_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, dh, float(scale), _stream()),
+         lambda: lib.nrv_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, dh, float(scale), int(layout), _stream()),
          "nrv_attn_fwd")
     return out, lse
 
 
-def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float,
+             layout: int = 0) -> Tensor:
     _bf16(qkv, "qkv"); _bf16(out, "out"); _bf16(dout, "dout"); _f32(lse, "lse")
     if not (qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()):
         raise NrvError("attn_bwd: operands must be contiguous")
@@ -282,16 +285,16 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, N: int
     lib = _lib.load()
     _run("attn_bwd", 10.0 * B * H * N * N * dh, 2 * B * N * H * dh * 8,
          lambda: lib.nrv_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                  delta.data_ptr(), B, N, H, dh, float(scale), _stream()),
+                                  delta.data_ptr(), B, N, H, dh, float(scale), int(layout), _stream()),
          "nrv_attn_bwd")
     return dqkv
 
 
-def attn_probs(qkv: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+def attn_probs(qkv: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float, layout: int = 0) -> Tensor:
     """fp32 [B, H, N, N] softmax probabilities recomputed from q, k and the saved log-sum-exp (introspection only)."""
     _bf16(qkv, "qkv"); _f32(lse, "lse")
     probs = torch.empty(B, H, N, N, dtype=torch.float32, device=qkv.device)
-    check(_lib.load().nrv_attn_probs(qkv.data_ptr(), lse.data_ptr(), probs.data_ptr(), B, N, H, dh, float(scale), _stream()),
+    check(_lib.load().nrv_attn_probs(qkv.data_ptr(), lse.data_ptr(), probs.data_ptr(), B, N, H, dh, float(scale), int(layout), _stream()),
           "nrv_attn_probs")
     return probs
 

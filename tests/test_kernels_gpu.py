@@ -403,6 +403,47 @@ def test_attention_fwd_bwd(dev, B, N, H):
     assert cos > 0.9995, cos
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 49, 2), (1, 256, 1), (2, 33, 2), (1, 1, 1), (4, 196, 12)])
+def test_attention_blocked_layouts_are_bit_equal_to_row_major(dev, B, N, H):
+    """NRV_ATTN_QKV_BLOCKED / NRV_ATTN_OUT_BLOCKED only change WHERE a head slice lies (qkv as [3H][B*N][64], out as
+    [H][B*N][64]): forward output, log-sum-exp, attention maps and the backward are bit-identical to the row-major call."""
+    k = _k()
+    dh, T = 64, B * N
+    scale = dh ** -0.5
+    qkv = rnd((T, 3 * H * dh), dev, 62, 1.0)
+    dout = rnd((T, H * dh), dev, 63, 1.0)
+
+    def blk(t, nb):
+        return t.reshape(T, nb, dh).permute(1, 0, 2).contiguous()
+
+    def unblk(t, nb):
+        return t.permute(1, 0, 2).reshape(T, nb * dh)
+
+    o0, lse0 = k.attn_fwd(qkv, B, N, H, dh, scale)
+    d0 = k.attn_bwd(qkv, o0, dout, lse0, B, N, H, dh, scale)
+    p0 = k.attn_probs(qkv, lse0, B, N, H, dh, scale)
+    for lay in (1, 2, 3):
+        q = blk(qkv, 3 * H) if lay & 1 else qkv
+        d = blk(dout, H) if lay & 2 else dout
+        o, lse = k.attn_fwd(q, B, N, H, dh, scale, layout=lay)
+        assert o.shape == ((H, T, dh) if lay & 2 else (T, H * dh))
+        dq = k.attn_bwd(q, o, d, lse, B, N, H, dh, scale, layout=lay)
+        assert torch.equal(unblk(o, H) if lay & 2 else o, o0), lay
+        assert torch.equal(lse, lse0), lay
+        assert torch.equal(unblk(dq, 3 * H) if lay & 1 else dq, d0), lay
+        assert torch.equal(k.attn_probs(q, lse, B, N, H, dh, scale, layout=lay), p0), lay
+
+
+def test_attention_blocked_layout_is_refused_where_it_is_not_implemented(dev):
+    from noise_robust_vit_amd._lib import NrvError
+    k = _k()
+    qkv = rnd((2 * 300, 3 * 2 * 64), dev, 64, 1.0)           # N = 300: the streaming kernels take the row-major form only
+    with pytest.raises(NrvError):
+        k.attn_fwd(qkv, 2, 300, 2, 64, 0.125, layout=1)
+    with pytest.raises(NrvError):
+        k.attn_fwd(rnd((2 * 64, 3 * 2 * 64), dev, 65, 1.0), 2, 64, 2, 64, 0.125, layout=4)
+
+
 # streaming kernels (csrc/nrv_attn_gen.hip): N > 256 and head dims 32 / 64 / 80 / 96 / 128 -- vit_h_14 (16 heads x 80, 257 tokens,
 # vit.py:512-519), ViT-B/16 at 384 px after interpolate_embeddings (577 tokens), SimpleViT(dim_head=...); partial last tiles,
 # a single tile, N a multiple of the tile

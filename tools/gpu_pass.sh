@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = a sequence of named steps, stopping at the first failure (no GPU step is started behind a failed one).
 #   bash tools/gpu_pass.sh TAG step1 step2 ...       outputs under gpurun_out/TAG/
-# steps: tests[:KEXPR]  bench[:ARCH[:extra flags]]  graphnodes:ARCH  gemmab:LIBS[:only]  stepab:LIBS[:ARCHS]  prof:ARCH  pmcsq:ARCH
+# steps: traffic[:ARCH[:BATCH]]  tests[:KEXPR]  bench[:ARCH[:extra flags]]  graphnodes:ARCH  gemmab:LIBS[:only]  stepab:LIBS[:ARCHS]  prof:ARCH  pmcsq:ARCH
 #        py:SCRIPT[:args]  (python tools/SCRIPT args)
 set -o pipefail
 TAG=$1; shift
@@ -46,6 +46,20 @@ for STEP in "$@"; do
         python tools/pmc_summary.py $F > $OUT/pmc_${N}_summary.txt 2>&1; head -40 $OUT/pmc_${N}_summary.txt
         rm -rf $OUT/pmc_$N
       done ;;
+    traffic)
+      A=${A1:-vit_b_16}; BATCH=${A2:-256}; RC=0
+      for C in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o c -- python3 $ROOT/bench.py --arch $A --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$C.log 2>&1); RC=$?
+        [ $RC -ne 0 ] && { tail -5 $OUT/pmc_$C.log; break; }
+      done
+      if [ $RC -eq 0 ]; then
+        F=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+        python tools/traffic_from_pmc.py $F $W $OUT/traffic_per_launch_${A}_b$BATCH.json > $OUT/traffic_$A.log 2>&1; tail -30 $OUT/traffic_$A.log
+        rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+      fi ;;
+    dbgagent)      # one command under the ROCm debug agent: on a GPU memory fault it prints the faulting waves (kernel, pc, registers)
+      HSA_TOOLS_LIB=/opt/rocm/lib/librocm-debug-agent.so.2 HSA_ENABLE_DEBUG=1 timeout -k 10 240 python $A1 $A2 > $OUT/dbgagent.log 2>&1; RC=$?
+      grep -v "^  node" $OUT/dbgagent.log | head -150 | cut -c1-300 ;;
     py)
       timeout -k 10 600 python tools/$A1 $A2 $A3 > $OUT/py_${A1%.py}.log 2>&1; RC=$?; tail -60 $OUT/py_${A1%.py}.log ;;
     *) echo "unknown step $NAME"; RC=9 ;;

@@ -123,5 +123,20 @@ for i in range(n.value):
     elif name != "empty":
         print(f"  node {i}: {name}")
 print("node kinds:", dict(kinds))
+# hipGraphMemcpyNodeGetParams returns nothing usable for the 1-D memcpy nodes a captured hipMemcpyAsync becomes: let the runtime
+# print them (hipGraphDebugDotPrint), and show every node of the dot file that is not a kernel
+dot = os.path.join(ROOT, "gpurun_out", f"graph_{arch}.dot")
+os.makedirs(os.path.dirname(dot), exist_ok=True)
+hip.hipGraphDebugDotPrint.argtypes = [C.c_void_p, C.c_char_p, C.c_uint]
+rc = hip.hipGraphDebugDotPrint(hgraph, dot.encode(), 1 | (1 << 3) | (1 << 4) | (1 << 10))
+print("hipGraphDebugDotPrint rc", rc, "exists", os.path.exists(dot))
+if os.path.exists(dot):
+    import re
+    txt = open(dot).read()
+    for lab in re.findall(r'label="([^"]*)"', txt):
+        low = lab.lower()
+        if "memcpy" in low or "memset" in low or "htod" in low or "dtoh" in low or "host" in low:
+            print("  dot:", lab.replace("\\n", " | ").replace("\n", " | ")[:500])
+    os.remove(dot)
 for k, v in knames.most_common(80):
     print(f"  {v:5d}  {k}")

@@ -6,7 +6,7 @@ traffic per kernel class, with the gfx950 corrections of MI355X_MICROARCH.md §H
 Usage: traffic_from_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
 import collections, csv, json, re, sys
 
-def load(path, counter):
+def load(path, counter, by_name=False):
     per = collections.defaultdict(lambda: [0.0, 0])
     seen = set()
     for r in csv.DictReader(open(path)):
@@ -20,6 +20,8 @@ def load(path, counter):
                "attn_bwd" if "attn_bwd" in name else "ln_fwd" if "ln_fwd" in name else "ln_bwd" if "ln_bwd" in name else None)
         if cls is None:
             continue
+        if by_name:
+            cls = re.sub(r"\(Gemm(NT|TN)Params\)|^void ", "", name)[:80]
         per[cls][0] += float(r["Counter_Value"])
         if key not in seen:
             seen.add(key)
@@ -34,5 +36,12 @@ for cls in sorted(set(fetch) | set(write)):
     n = max(nf, nw, 1)
     out["per_launch_bytes"][cls] = {"launches_profiled": n, "read": round(2 * f * 1024 / n), "write": round(w * 1024 / n),
                                     "total": round((2 * f + w) * 1024 / n)}
+# the same per kernel NAME (the GEMM's tile / epilogue template arguments): which launches move what
+fetch_n, write_n = load(sys.argv[1], "FETCH_SIZE", True), load(sys.argv[2], "WRITE_SIZE", True)
+out["per_launch_bytes_by_kernel"] = {}
+for name in sorted(set(fetch_n) | set(write_n)):
+    f, nf = fetch_n.get(name, [0, 0]); w, nw = write_n.get(name, [0, 0])
+    n = max(nf, nw, 1)
+    out["per_launch_bytes_by_kernel"][name] = {"launches_profiled": n, "read": round(2 * f * 1024 / n), "write": round(w * 1024 / n)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["per_launch_bytes"], indent=1))
