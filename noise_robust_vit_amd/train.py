@@ -145,8 +145,7 @@ class Trainer:
         return loss
 
     # ---- whole-step HIP graph -------------------------------------------------------------------
-    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2, keep_graph: bool = False,
-                _allow_custom_loss: bool = False) -> None:
+    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2, keep_graph: bool = False) -> None:
         """Capture forward + loss + backward + clip + AdamW + weight re-staging (one training step, ~370 - 830 kernel launches)
         into ONE HIP graph; afterwards `step()` copies the batch into the captured input buffers, refreshes three device
         scalars (learning rate, bias corrections) and replays the graph.  What this removes is the host: 13 ms of ctypes /
@@ -158,11 +157,6 @@ class Trainer:
             raise RuntimeError("Trainer.capture needs the MI355X path (FusedAdamW)")
         if self.cfg.cutmix_prob > 0.0:
             raise RuntimeError("Trainer.capture: CutMix draws its box on the host every step and cannot be replayed")
-        if self.compute_loss is not None and not _allow_custom_loss:
-            # the MAE step (per-sample random permutation -> library sort -> index gathers) faulted on the GPU in its first
-            # replay (profiles/r03_graph_capture_eager_vs_replay_and_mae_fault.txt); only the classification step, whose
-            # replay is tested bit-equal to the eager step, is captured
-            raise RuntimeError("Trainer.capture: only the classification step (model(x) -> cross entropy) is captured")
         if self.reducer is not None and (self.reducer.world > 1 or self.reducer.force):
             raise RuntimeError("Trainer.capture: collectives are not captured; use the eager step with a process group")
         opt = self.opt

@@ -1,6 +1,7 @@
 """GPU parity of the fused optimizer step (csrc/nrv_optim.hip) against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW --
 the arithmetic the reference harness runs (examples/CIFAR100.py:90-97,191-192).  fp32 elementwise math: 2e-6 relative."""
 import copy
+import math
 
 import pytest
 import torch
@@ -108,6 +109,82 @@ def test_graph_replay_of_the_whole_step_is_bit_equal_to_the_eager_step(dev):
     assert replayed == eager, (replayed, eager)
     for k, v in m2.state_dict().items():
         assert torch.equal(v, p1[k]), k
+
+
+def _mae_small(dev):
+    from noise_robust_vit_amd.encoder import WEIGHTS
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from noise_robust_vit_amd.mae import MAE
+    torch.manual_seed(0)
+    WEIGHTS.clear()
+    enc = ViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256)
+    return MAE(encoder=enc, decoder_dim=64, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, decoder_dim_head=64).to(dev).train()
+
+
+def test_graph_replay_of_the_mae_step_is_bit_equal_to_the_eager_step(dev):
+    """The MAE step under Trainer.capture (round 3: GPU memory fault in the first replay, then refused; round 4: the row gather /
+    scatter kernels take the source-row count and range-check the device-side indices, ABI 11, and the refusal is gone).
+    The per-sample permutation travels in `y` here, so the captured gather / scatter / index bookkeeping runs on another
+    permutation at every replay: losses and every parameter after 4 steps must equal the eager run bit for bit."""
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+
+    def make():
+        m = _mae_small(dev)
+        return m, Trainer(m, TrainConfig(lr=1e-3, weight_decay=0.05, grad_max_norm=1.0, warmup_steps=2, cosine_steps=6),
+                          compute_loss=lambda mod, xb, yb: mod(xb, rand_indices=yb))
+
+    g = torch.Generator(device=dev).manual_seed(17)
+    xs = [torch.randn(8, 3, 64, 64, generator=g, device=dev).to(torch.bfloat16) for _ in range(4)]
+    ys = [torch.rand(8, 16, generator=g, device=dev).argsort(dim=-1) for _ in range(4)]
+    m1, t1 = make()
+    eager = [t1.step(x, y).item() for x, y in zip(xs, ys)]
+    p1 = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+    m2, t2 = make()
+    first = t2.step(xs[0], ys[0]).item()
+    t2.capture(xs[1], ys[1])
+    replayed = [first] + [t2.step(x, y).item() for x, y in zip(xs[1:], ys[1:])]
+    assert replayed == eager, (replayed, eager)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, p1[k]), k
+
+
+def test_graph_replay_of_the_mae_step_draws_a_fresh_mask_every_replay(dev):
+    """Default MAE forward (mae.py:66-71: torch.rand(...).argsort() inside the step): under replay the captured random draw
+    takes a new Philox offset every time (torch's graph-safe generator), i.e. the mask changes from step to step, the loss
+    stays finite and at the level of the eager steps, and the device-side indices stay inside the token range (the gather's
+    output holds no all-zero row, which is what an out-of-range index produces since ABI 11)."""
+    from noise_robust_vit_amd import kernels as K
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    m = _mae_small(dev)
+    t = Trainer(m, TrainConfig(lr=1e-3, weight_decay=0.05, grad_max_norm=1.0), compute_loss=lambda mod, xb, yb: mod(xb))
+    g = torch.Generator(device=dev).manual_seed(23)
+    x = torch.randn(8, 3, 64, 64, generator=g, device=dev).to(torch.bfloat16)
+    y = torch.zeros(8, dtype=torch.int64, device=dev)
+    eager = [t.step(x, y).item() for _ in range(3)]
+    seen = []
+    orig = K.gather_rows
+
+    def spy(src, index):
+        out = orig(src, index)
+        seen.append((index, out))                 # tensors of the graph's pool: read after each replay
+        return out
+
+    K.gather_rows = spy
+    try:
+        t.capture(x, y)
+    finally:
+        K.gather_rows = orig
+    index, out = seen[-1]                         # the capture's own call: static buffers of the replayed graph
+    masks, losses = [], []
+    for _ in range(3):
+        losses.append(t.step(x, y).item())
+        torch.cuda.synchronize()
+        masks.append(index.clone())
+        assert int(index.min()) >= 0 and int(index.max()) < 8 * 16
+        assert bool((out.abs().sum(dim=1) > 0).all())
+    assert all(math.isfinite(v) for v in losses)
+    assert max(losses) < 2.0 * max(eager) and min(losses) > 0.3 * min(eager), (losses, eager)
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
 
 
 def test_weight_gradients_on_the_side_stream_follow_the_one_stream_trajectory(dev):

@@ -27,7 +27,7 @@ y = torch.randint(0, 1000, (batch,), generator=g, device=dev)
 for _ in range(2):
     trainer.step(x, y)
 torch.cuda.synchronize()
-trainer.capture(x, y, keep_graph=True, _allow_custom_loss=True)
+trainer.capture(x, y, keep_graph=True)
 graph = trainer._graph
 trainer._graph = None                   # never replayed here
 torch.cuda.synchronize()
