@@ -164,7 +164,9 @@ int nrv_attn_probs(const void* qkv_bf16, const float* lse, float* probs,
 /* "robust" attention (robust=True): softmax followed by Sinkhorn normalisation -- 3 x (row /, column /) and a final
  * row / -- utils.py:1025-1037, wired at simple_vit.py:56-57.  Same layouts as nrv_attn_fwd.
  *   scalings fp32 [B, H, 7, N]: the row / column scaling vectors a1 b1 a2 b2 a3 b3 a4 (cumulative: after step t, P = diag(a_t) softmax(S) diag(b_t); the final matrix is diag(a4) softmax(S) diag(b3)),
- *   saved with lse for the backward.  dh == 64, N <= 256.  The backward is one kernel and needs no scratch (ABI 8). */
+ *   saved with lse for the backward.  dh == 64, N <= 256 (the head's [N,N] matrix stays on chip); other shapes return
+ *   NRV_ERR_SHAPE -- the host side composes them from nrv_bgemm + nrv_sinkhorn_fwd / bwd (kernels.attn_sinkhorn_*).
+ *   The backward is one kernel and needs no scratch (ABI 8). */
 int nrv_attn_sinkhorn_fwd(const void* qkv_bf16, void* out_bf16, float* lse, float* scalings,
                           int B, int N, int H, int dh, float scale, void* stream);
 int nrv_attn_sinkhorn_bwd(const void* qkv_bf16, const void* dout_bf16, const float* lse, const float* scalings,
@@ -183,6 +185,20 @@ int nrv_sinkhorn_fwd(const float* scores, float* out, float* lse, float* avec, f
                      int64_t G, int R, int C, int iters, void* stream);
 int nrv_sinkhorn_bwd(const float* scores, const float* dout, const float* lse, const float* avec, const float* bvec,
                      float* dscores, int64_t G, int R, int C, int iters, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched small GEMM with arbitrary strides (bf16 MFMA, fp32 accumulation): for every (g1 < G1, g2 < G2)
+ *   C[g1,g2][m,n] = alpha * sum_k A[g1,g2][m,k] * B[g1,g2][k,n],   element (g1, g2, row, col) of an operand at
+ *   base + g1 * b1 + g2 * b2 + row * rs + col * cs  (ELEMENT strides; dtype fp32 or bf16 per operand; operands are rounded to
+ *   bf16 when staged).  The matrix products of robust=True attention at the shapes the fused nrv_attn_sinkhorn_* kernels do
+ *   not take (N > 256 or dh != 64) -- the reference's own structure there: q k^T * scale (simple_vit.py:70), SinkhornAttention on
+ *   the materialised scores (utils.py:1031-1037 = nrv_sinkhorn_fwd / bwd), attn v (simple_vit.py:74), and their backward --
+ *   read head slices of the packed projection and write slices of dqkv in place through the strides.  ABI 11.
+ * ---------------------------------------------------------------------------------------- */
+int nrv_bgemm(const void* A, int a_dtype, int64_t a_rs, int64_t a_cs, int64_t a_b1, int64_t a_b2,
+              const void* B, int b_dtype, int64_t b_rs, int64_t b_cs, int64_t b_b1, int64_t b_b2,
+              void* C, int c_dtype, int64_t c_rs, int64_t c_cs, int64_t c_b1, int64_t c_b2,
+              int G1, int G2, int M, int N, int K, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch unfold (replaces einops Rearrange 'b c (h p1) (w p2) -> b h w (p1 p2 c)' simple_vit.py:126-129,

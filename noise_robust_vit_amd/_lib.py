@@ -60,6 +60,8 @@ SIGNATURES = {
                               c_double, c_double, c_double, c_double, c_double, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "nrv_sinkhorn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "nrv_sinkhorn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "nrv_bgemm": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
+                          c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "nrv_set_reserved_cus": (c_int, [c_int]),
     "nrv_probe": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p]),
 }

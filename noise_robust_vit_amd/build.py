@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnrv_hip.so")
-SOURCES = ["nrv_gemm.hip", "nrv_norm.hip", "nrv_attn.hip", "nrv_attn_gen.hip", "nrv_misc.hip", "nrv_sinkhorn.hip", "nrv_sinknorm.hip", "nrv_optim.hip"]
+SOURCES = ["nrv_gemm.hip", "nrv_norm.hip", "nrv_attn.hip", "nrv_attn_gen.hip", "nrv_misc.hip", "nrv_sinkhorn.hip", "nrv_sinknorm.hip", "nrv_optim.hip", "nrv_bgemm.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wall", "-Wno-unused-function"]

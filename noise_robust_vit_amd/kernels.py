@@ -299,11 +299,20 @@ def attn_probs(qkv: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale:
     return probs
 
 
+def _sinkhorn_fused_shape(N: int, dh: int) -> bool:
+    """Shapes the fused kernels hold on chip (csrc/nrv_sinkhorn.hip): the head's whole [N, N] matrix in registers."""
+    return dh == 64 and N <= 256
+
+
 def attn_sinkhorn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
-    """robust=True attention (utils.py:1025-1037): returns (out bf16, lse fp32 [B,H,N], scalings fp32 [B,H,7,N])."""
+    """robust=True attention (utils.py:1025-1037): returns (out bf16, lse fp32 [B,H,N], scalings fp32 [B,H,7,N]).
+    N <= 256 and dh == 64: the fused kernel.  Any other shape (vit_h_14, 384-px checkpoints, other head dims): composed from
+    the batched GEMM and the stand-alone Sinkhorn op on materialised [B,H,N,N] scores -- the reference's own structure."""
     _bf16(qkv, "qkv")
     if not qkv.is_contiguous() or qkv.numel() != B * N * 3 * H * dh:
         raise NrvError("attn_sinkhorn_fwd: qkv must be contiguous [B*N, 3*H*dh]")
+    if not _sinkhorn_fused_shape(N, dh):
+        return _attn_sinkhorn_fwd_composed(qkv, B, N, H, dh, scale)
     out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     scal = torch.empty(B, H, 7, N, dtype=torch.float32, device=qkv.device)
@@ -319,12 +328,89 @@ def attn_sinkhorn_bwd(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: i
     _bf16(qkv, "qkv"); _bf16(dout, "dout"); _f32(lse, "lse"); _f32(scal, "scal")
     if not (qkv.is_contiguous() and dout.is_contiguous()):
         raise NrvError("attn_sinkhorn_bwd: operands must be contiguous")
+    if not _sinkhorn_fused_shape(N, dh):
+        return _attn_sinkhorn_bwd_composed(qkv, dout, lse, scal, B, N, H, dh, scale)
     dqkv = torch.empty_like(qkv)
     lib = _lib.load()
     _run("attn_sinkhorn_bwd", 10.0 * B * H * N * N * dh, 2 * B * N * H * dh * 7,
          lambda: lib.nrv_attn_sinkhorn_bwd(qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), scal.data_ptr(), dqkv.data_ptr(),
                                            B, N, H, dh, float(scale), _stream()),
          "nrv_attn_sinkhorn_bwd")
+    return dqkv
+
+
+# ---- batched strided GEMM + the composed robust attention -----------------------------------------------------------------
+def bgemm(A, a_str, B_, b_str, C, c_str, G1: int, G2: int, M: int, N: int, K: int, alpha: float = 1.0) -> None:
+    """C[g1,g2] = alpha * A[g1,g2] . B[g1,g2] (include/nrv.h nrv_bgemm).  A, B, C: (tensor, element offset) pairs; *_str =
+    (row stride, column stride, g1 stride, g2 stride) in elements.  The tensors are only memory: the strides do the addressing,
+    and the caller guarantees that every addressed element lies inside its tensor (checked below)."""
+    lib = _lib.load()
+    ptrs = []
+    for (t, off), st, rows, cols, name in ((A, a_str, M, K, "A"), (B_, b_str, K, N, "B"), (C, c_str, M, N, "C")):
+        _dev(t, name)
+        last = off + (rows - 1) * st[0] + (cols - 1) * st[1] + (G1 - 1) * st[2] + (G2 - 1) * st[3]
+        if off < 0 or min(st) < 0 or last >= t.numel():
+            raise NrvError(f"bgemm: operand {name} addresses element {last} of a tensor with {t.numel()}")
+        ptrs.append((t.data_ptr() + off * t.element_size(), _dt(t, name)))
+    _run("bgemm", 2.0 * G1 * G2 * M * N * K, 0.0,
+         lambda: lib.nrv_bgemm(ptrs[0][0], ptrs[0][1], *[int(v) for v in a_str], ptrs[1][0], ptrs[1][1], *[int(v) for v in b_str],
+                               ptrs[2][0], ptrs[2][1], *[int(v) for v in c_str], G1, G2, M, N, K, float(alpha), _stream()),
+         "nrv_bgemm")
+
+
+def _head_strides(H: int, dh: int, width: int, N: int):
+    """(row, col, batch, head) element strides of one head's [N, dh] slice inside a [B*N, width] projection."""
+    return (width, 1, N * width, dh)
+
+
+def _sinkhorn_scores(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+    """S[b,h] = scale * q k^T, fp32 [B,H,N,N] (simple_vit.py:70)."""
+    W = 3 * H * dh
+    rs, cs, bs, hs = _head_strides(H, dh, W, N)
+    S = torch.empty(B, H, N, N, dtype=torch.float32, device=qkv.device)
+    bgemm((qkv, 0), (rs, cs, bs, hs), (qkv, H * dh), (cs, rs, bs, hs), (S, 0), (N, 1, H * N * N, N * N), B, H, N, N, dh, scale)
+    return S
+
+
+def _attn_sinkhorn_fwd_composed(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
+    W = 3 * H * dh
+    rs, cs, bs, hs = _head_strides(H, dh, W, N)
+    S = _sinkhorn_scores(qkv, B, N, H, dh, scale)
+    P, lse, avec, bvec = sinkhorn_fwd(S, iters=3)                 # SinkhornAttention on the materialised scores (utils.py:1031-1037)
+    del S
+    out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
+    ors, ocs, obs, ohs = _head_strides(H, dh, H * dh, N)
+    # O[b,h] = P7 v   (attn v, simple_vit.py:74; P7 enters the product in bf16 as in the fused kernels)
+    bgemm((P, 0), (N, 1, H * N * N, N * N), (qkv, 2 * H * dh), (rs, cs, bs, hs), (out, 0), (ors, ocs, obs, ohs), B, H, N, dh, N, 1.0)
+    # the model keeps ONE form of the saved statistics: [B,H,7,N] = a1 b1 a2 b2 a3 b3 a4 (cumulative), as the fused kernel writes it
+    scal = torch.empty(B, H, 7, N, dtype=torch.float32, device=qkv.device)
+    scal[:, :, 0::2] = avec.reshape(B, H, 4, N)
+    scal[:, :, 1::2] = bvec.reshape(B, H, 3, N)
+    return out, lse.reshape(B, H, N), scal
+
+
+def _attn_sinkhorn_bwd_composed(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+    W = 3 * H * dh
+    rs, cs, bs, hs = _head_strides(H, dh, W, N)
+    ors, ocs, obs, ohs = _head_strides(H, dh, H * dh, N)
+    mat = (N, 1, H * N * N, N * N)                                 # a [B,H,N,N] fp32 matrix
+    matT = (1, N, H * N * N, N * N)                                # ... read transposed
+    S = _sinkhorn_scores(qkv, B, N, H, dh, scale)                  # recomputed: nothing [N,N]-sized is kept between the passes
+    P, _, _, _ = sinkhorn_fwd(S, iters=3)
+    avec = scal[:, :, 0::2].reshape(B * H, 4, N).contiguous()
+    bvec = scal[:, :, 1::2].reshape(B * H, 3, N).contiguous()
+    dqkv = torch.empty_like(qkv)
+    # dV = P7^T dO
+    bgemm((P, 0), matT, (dout, 0), (ors, ocs, obs, ohs), (dqkv, 2 * H * dh), (rs, cs, bs, hs), B, H, N, dh, N, 1.0)
+    # dP7 = dO v^T, reusing P's storage would alias an operand of nothing that follows: a buffer of its own keeps it simple
+    dP = torch.empty_like(P)
+    bgemm((dout, 0), (ors, ocs, obs, ohs), (qkv, 2 * H * dh), (cs, rs, bs, hs), (dP, 0), mat, B, H, N, N, dh, 1.0)
+    del P
+    dS = sinkhorn_bwd(S, dP, lse.reshape(B * H, N).contiguous(), avec, bvec, iters=3)
+    del dP, S
+    # dQ = scale dS k ;  dK = scale dS^T q
+    bgemm((dS, 0), mat, (qkv, H * dh), (rs, cs, bs, hs), (dqkv, 0), (rs, cs, bs, hs), B, H, N, dh, N, scale)
+    bgemm((dS, 0), matT, (qkv, 0), (rs, cs, bs, hs), (dqkv, H * dh), (rs, cs, bs, hs), B, H, N, dh, N, scale)
     return dqkv
 
 

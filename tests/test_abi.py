@@ -102,9 +102,14 @@ def test_loader_sets_prototypes_and_reports_errors(lib_path):
     assert lib.nrv_gemm_nt_bf16(None, 8, None, 8, None, 1, 8, 8, 8, 8, 0, None, None, 0, 0, 0, None, 0, 0, 0, 0, None) == -1
     # shapes are classified before anything else touches the (here: bogus, unaligned) pointers: the streaming kernels take
     # N > 256 and head dims 32 / 64 / 80 / 96 / 128 (the call then fails on the alignment check, -5), other dims are refused
-    assert lib.nrv_attn_fwd(1, 1, 1, 1, 300, 1, 64, ctypes.c_float(0.125), None) == -5          # N > 256: accepted shape
-    assert lib.nrv_attn_fwd(1, 1, 1, 1, 257, 16, 80, ctypes.c_float(0.125), None) == -5         # vit_h_14 geometry
-    assert lib.nrv_attn_fwd(1, 1, 1, 1, 10, 1, 72, ctypes.c_float(0.125), None) == -2           # unsupported head dim
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 300, 1, 64, ctypes.c_float(0.125), 0, None) == -5       # N > 256: accepted shape
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 257, 16, 80, ctypes.c_float(0.125), 0, None) == -5      # vit_h_14 geometry
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 10, 1, 72, ctypes.c_float(0.125), 0, None) == -2        # unsupported head dim
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 197, 12, 64, ctypes.c_float(0.125), 3, None) == -5      # blocked layouts: single-pass shapes
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 300, 1, 64, ctypes.c_float(0.125), 1, None) == -2       # ... not the streaming kernels
+    assert lib.nrv_attn_fwd(1, 1, 1, 1, 197, 12, 64, ctypes.c_float(0.125), 4, None) == -2      # unknown layout bit
+    assert lib.nrv_gather_rows_f32(16, 16, 16, 4, 0, 64, None) == -2                            # ABI 11: the source-row count is required
+    assert lib.nrv_bgemm(None, 1, 1, 1, 0, 0, 16, 1, 1, 1, 0, 0, 16, 0, 1, 1, 0, 0, 1, 1, 8, 8, 8, ctypes.c_float(1.0), None) == -1
     assert lib.nrv_attn_sinkhorn_fwd(1, 1, 1, 1, 1, 300, 1, 64, ctypes.c_float(0.125), None) == -2   # Sinkhorn: N <= 256 only
     assert lib.nrv_layernorm_fwd(16, 0, 16, 16, 16, 16, 16, 4, 12, ctypes.c_float(1e-5), None) == -2   # dim % 8
     assert b"shape" in lib.nrv_error_string(-2)

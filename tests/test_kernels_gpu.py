@@ -544,6 +544,100 @@ def test_sinkhorn_attention_fwd_bwd(dev, B, N, H):
     assert rel < 3e-2 and cos > 0.999, (rel, cos)
 
 
+# robust=True beyond the fused kernels' shapes (N > 256 or dh != 64): composed from nrv_bgemm + nrv_sinkhorn_fwd / bwd on the
+# materialised scores -- vit_h_14 (257 tokens, 16 heads x 80), ViT-B/16 at 384 px (577 tokens), SimpleViT(dim_head = 32 / 96 / 128)
+@pytest.mark.parametrize("B,N,H,dh", [(2, 257, 4, 80), (1, 577, 3, 64), (2, 400, 2, 32), (2, 100, 3, 96), (1, 300, 2, 128), (3, 17, 2, 32)])
+def test_sinkhorn_attention_composed_any_n_and_head_dim(dev, B, N, H, dh):
+    k = _k()
+    scale = dh ** -0.5
+    qkv = rnd((B * N, 3 * H * dh), dev, 65, 1.0)
+    out, lse, scal = k.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
+    assert scal.shape == (B, H, 7, N) and lse.shape == (B, H, N)
+    qr = qkv.float().requires_grad_(True)
+    ref_o, P = sinkhorn_ref(qr, B, N, H, dh, scale)
+    err = (out.float() - ref_o).abs().max().item() / ref_o.abs().max().item()
+    assert err < 2 ** -6, err
+    q_, k_, _ = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    s_ = (q_ @ k_.transpose(-1, -2)) * scale
+    assert (lse - torch.logsumexp(s_, dim=-1)).abs().max().item() < 1e-4
+    P7 = scal[:, :, 6, :, None] * torch.softmax(s_, dim=-1) * scal[:, :, 5, None, :]
+    assert (P7 - P.detach()).abs().max().item() < 1e-4 * P.max().item() + 1e-6
+    dout = rnd((B * N, H * dh), dev, 66, 1.0)
+    ref_o.backward(dout.float())
+    dqkv = k.attn_sinkhorn_bwd(qkv, dout, lse, scal, B, N, H, dh, scale)
+    g, r = dqkv.float().reshape(-1), qr.grad.reshape(-1)
+    rel = ((g - r).norm() / r.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
+    assert rel < 3e-2 and cos > 0.999, (rel, cos)
+    # and the attention maps the Recorder exports for these shapes
+    a, b = scal[:, :, 6], scal[:, :, 5]
+    maps = k.attn_probs(qkv, lse, B, N, H, dh, scale) * a[..., :, None] * b[..., None, :]
+    assert (maps - P.detach()).abs().max().item() < 2e-3 * P.max().item() + 1e-6
+
+
+def test_sinkhorn_attention_composed_matches_the_fused_kernel_where_both_run(dev):
+    """N = 197, dh = 64: the composed path (forced) against the fused kernels on the same data -- same rounding points (P7 and dS
+    enter their products in bf16), other summation orders."""
+    k = _k()
+    B, N, H, dh = 2, 197, 3, 64
+    scale = dh ** -0.5
+    qkv = rnd((B * N, 3 * H * dh), dev, 67, 1.0)
+    dout = rnd((B * N, H * dh), dev, 68, 1.0)
+    o1, lse1, scal1 = k.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
+    d1 = k.attn_sinkhorn_bwd(qkv, dout, lse1, scal1, B, N, H, dh, scale)
+    o2, lse2, scal2 = k._attn_sinkhorn_fwd_composed(qkv, B, N, H, dh, scale)
+    d2 = k._attn_sinkhorn_bwd_composed(qkv, dout, lse2, scal2, B, N, H, dh, scale)
+    assert (lse1 - lse2).abs().max().item() < 1e-4
+    assert ((scal1 - scal2).abs() / scal1.abs().clamp_min(1e-6)).max().item() < 1e-3
+    assert (o1.float() - o2.float()).abs().max().item() <= 2 ** -6 * o1.float().abs().max().item()
+    rel = ((d1.float() - d2.float()).norm() / d1.float().norm()).item()
+    assert rel < 1e-2, rel
+
+
+@pytest.mark.parametrize("case", ["head_slices", "transposed_a", "fp32_to_bf16", "tails"])
+def test_bgemm_strided_batches(dev, case):
+    """nrv_bgemm against torch on the same bf16-rounded operands: head slices of a packed projection, a transposed operand, an
+    fp32 operand rounded on staging, odd sizes (tile tails in M, N and K)."""
+    k = _k()
+    g = torch.Generator(device=dev).manual_seed(71)
+    if case == "head_slices":                 # S[b,h] = 0.5 q k^T from a [B*N, 3*H*dh] projection
+        B, N, H, dh = 2, 70, 3, 32
+        W = 3 * H * dh
+        qkv = rnd((B * N, W), dev, 72, 1.0)
+        S = torch.empty(B, H, N, N, device=dev)
+        k.bgemm((qkv, 0), (W, 1, N * W, dh), (qkv, H * dh), (1, W, N * W, dh), (S, 0), (N, 1, H * N * N, N * N), B, H, N, N, dh, 0.5)
+        q_, k_, _ = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        ref = 0.5 * (q_ @ k_.transpose(-1, -2))
+        assert rel_err(S, ref) < 1e-5
+    elif case == "transposed_a":              # C[g] = A[g]^T B[g], bf16 output
+        G, M, N, K = 3, 50, 40, 130
+        A = rnd((G, K, M), dev, 73, 1.0)
+        Bm = rnd((G, K, N), dev, 74, 1.0)
+        C = torch.empty(G, M, N, dtype=torch.bfloat16, device=dev)
+        k.bgemm((A, 0), (1, M, K * M, 0), (Bm, 0), (N, 1, K * N, 0), (C, 0), (N, 1, M * N, 0), G, 1, M, N, K, 1.0)
+        ref = A.float().transpose(1, 2) @ Bm.float()
+        assert (C.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6
+    elif case == "fp32_to_bf16":              # an fp32 operand is rounded to bf16 when it is staged
+        G, M, N, K = 2, 64, 64, 96
+        A = torch.randn(G, M, K, generator=g, device=dev)
+        Bm = rnd((G, K, N), dev, 75, 1.0)
+        C = torch.empty(G, M, N, device=dev)
+        k.bgemm((A, 0), (K, 1, M * K, 0), (Bm, 0), (N, 1, K * N, 0), (C, 0), (N, 1, M * N, 0), G, 1, M, N, K, 2.0)
+        ref = 2.0 * (A.to(torch.bfloat16).float() @ Bm.float())
+        assert rel_err(C, ref) < 1e-5
+    else:
+        G, M, N, K = 1, 65, 129, 33
+        A = rnd((M, K), dev, 76, 1.0)
+        Bm = rnd((K, N), dev, 77, 1.0)
+        C = torch.full((M + 1, N + 3), 7.0, device=dev)          # canary: nothing outside [0:M, 0:N] is written
+        k.bgemm((A, 0), (K, 1, 0, 0), (Bm, 0), (N, 1, 0, 0), (C, 0), (N + 3, 1, 0, 0), 1, 1, M, N, K, 1.0)
+        assert rel_err(C[:M, :N], A.float() @ Bm.float()) < 1e-5
+        assert bool((C[M:] == 7.0).all()) and bool((C[:, N:] == 7.0).all())
+        from noise_robust_vit_amd._lib import NrvError
+        with pytest.raises(NrvError):             # an operand that addresses memory outside its tensor is refused on the host
+            k.bgemm((A, 0), (K, 1, 0, 0), (Bm, 0), (N, 1, 0, 0), (C, 0), (N + 3, 1, 0, 0), 1, 1, M + 2, N, K, 1.0)
+
+
 # ------------------------------------------------------------------ data movement
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -339,6 +339,64 @@ def test_vision_transformer_robust_vit_b_geometry_against_oracle(dev):
     assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
 
 
+@pytest.mark.parametrize("case", ["vit_h_14_l1", "vit_b_16_384px_l1"])
+def test_vision_transformer_robust_beyond_the_fused_shapes_against_oracle(dev, case):
+    """robust=True where the head's [N, N] matrix does not stay on chip -- vit_h_14 (257 tokens, 16 heads x 80; vit.py:512-519)
+    and ViT-B/16 at 384 px (577 tokens) -- runs the composed path (nrv_bgemm + SinkhornAttention on materialised scores,
+    kernels._attn_sinkhorn_*_composed): logits, loss and every parameter gradient against the CPU oracle (round 3: NrvError)."""
+    from noise_robust_vit_amd import VisionTransformer
+    from oracle import vit_oracle as V
+    from oracle.simple_vit_oracle import cross_entropy_ls
+    cfg, B, tol_ref, tol_emu, tol_grad = VT_CASES[case]
+    sd = V.vit_init_state_dict(seed=3, **cfg)
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        if k.endswith("bias") or k == "class_token":
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    model = VisionTransformer(**cfg, robust=True)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    x = torch.randn(B, 3, cfg["image_size"], cfg["image_size"], generator=g)
+    y = torch.randint(0, cfg["num_classes"], (B,), generator=g)
+    logits = model(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.1)
+    loss.backward()
+    torch.set_num_threads(8)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = V.vit_forward(leaves, x, patch_size=cfg["patch_size"], num_heads=cfg["num_heads"], robust=True)
+    ref_loss = cross_entropy_ls(ref, y)
+    ref_loss.backward()
+    emu = V.vit_forward(sd, x, patch_size=cfg["patch_size"], num_heads=cfg["num_heads"], robust=True, emulate_bf16=True)
+    e_ref, e_emu = relmax(logits, ref), relmax(logits, emu)
+    worst = check_grads(model, {k: v.grad for k, v in leaves.items()}, tol=tol_grad)
+    print(f"VT robust {case}: logits vs fp32 oracle {e_ref:.3e}, vs emulating oracle {e_emu:.3e}, "
+          f"loss {loss.item():.6f} vs {ref_loss.item():.6f}, worst grad rel-L2 {worst[0]:.3e} ({worst[1]})")
+    assert e_ref < tol_ref and e_emu < tol_emu
+    assert abs(loss.item() - ref_loss.item()) < LOSS_TOL_FP32REF
+
+
+def test_simplevit_robust_with_other_head_dim(dev):
+    """SimpleViT(dim_head=32, robust=True) (simple_vit.py:56-57,101-114): Sinkhorn attention at a head dim the fused kernel does
+    not take -- the composed path, against the oracle with all gradients."""
+    from noise_robust_vit_amd import SimpleViT
+    from oracle import simple_vit_oracle as O
+    torch.manual_seed(0)
+    model = SimpleViT(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=3, mlp_dim=256, dim_head=32, robust=True)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    y = torch.randint(0, 10, (3,), generator=torch.Generator().manual_seed(4))
+    logits = model(x.to(dev))
+    torch.nn.functional.cross_entropy(logits, y.to(dev), label_smoothing=0.1).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.simple_vit_forward(leaves, x, patch_size=16, heads=3, dim_head=32, robust=True)
+    O.cross_entropy_ls(ref, y).backward()
+    emu = O.simple_vit_forward(sd, x, patch_size=16, heads=3, dim_head=32, robust=True, emulate_bf16=True)
+    assert relmax(logits, ref) < LOGIT_TOL_FP32REF, relmax(logits, ref)
+    assert relmax(logits, emu) < LOGIT_TOL_EMULATED, relmax(logits, emu)
+    check_grads(model, {k: v.grad for k, v in leaves.items()}, tol=GRAD_RELL2_TOL)
+
+
 ROBUST_VT_BOUNDS = (1.0e-2, 6.4e-3, 1.5e-2)      # measured on MI355X: 5.0e-3, 3.2e-3, 7.7e-3 (conv_proj.weight); loss 2.48822 vs 2.48793
 
 
