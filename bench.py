@@ -34,7 +34,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r03"
+ROUND = "r04"
 
 
 def _vit(L, H, D, M):
@@ -197,11 +197,11 @@ def main():
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient exchange precision (N > 1)")
     ap.add_argument("--bucket-mib", type=float, default=64.0, help="all-reduce bucket size")
     ap.add_argument("--tail-mib", type=float, default=8.0, help="cap of the last (non-overlappable) bucket")
-    ap.add_argument("--rccl-max-ctas", type=int, default=-1,
-                    help="CU budget of RCCL's kernels (-1: 8 when N > 1 -- the 605 MB a ViT-B/16 step exchanges per GPU hide behind a 33 ms "
-                         "backward at a fraction of the xGMI rate --, 0: RCCL's default)")
-    ap.add_argument("--reserve-cus", type=int, default=-1,
-                    help="CUs the GEMM launches leave free for the collective's kernels when N > 1 (-1: the RCCL budget; 0: none)")
+    ap.add_argument("--rccl-max-ctas", type=int, default=0,
+                    help="CU budget of RCCL's kernels (0: RCCL's default -- what runs at N > 1 until an N > 1 A/B exists; 8 was reasoned for "
+                         "the 605 MB a ViT-B/16 step exchanges per GPU, never measured)")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="CUs the GEMM launches leave free for the collective's kernels when N > 1 (0: none, the default; unmeasured at N > 1)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (Trainer.capture)")
     args = ap.parse_args()
 
@@ -228,10 +228,8 @@ def main():
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if args.rccl_max_ctas < 0:
-            args.rccl_max_ctas = 8 if world > 1 else 0
-        if args.reserve_cus < 0:
-            args.reserve_cus = args.rccl_max_ctas if world > 1 else 0
+        args.rccl_max_ctas = max(args.rccl_max_ctas, 0)
+        args.reserve_cus = max(args.reserve_cus, 0) if world > 1 else 0
         pg_desc = make_process_group(rank, world, device=dev, backend="nccl", max_ctas=args.rccl_max_ctas)   # "nccl" IS RCCL on ROCm
 
     kind = ARCHS[args.arch][0]
@@ -302,8 +300,8 @@ def main():
                                    f"GEMM launches planned for the device's CUs minus {reducer.reserve_cus}"
                                    + (", forced at world 1" if world == 1 else ", overlapped with backward")),
                    "launch": "one HIP graph per step (Trainer.capture)" if args.graph else "eager (one C-ABI call per kernel)",
-                   "streams": "weight-gradient GEMMs on a second HIP stream where the dX grid leaves >= 15 % of its CU-rounds idle "
-                              "(encoder.WGRAD_STREAM = auto; not on ViT-B/16 at batch 256); the per-launch timing leg runs on one stream",
+                   "streams": "the layer's grouped weight-gradient launch goes to a second HIP stream where the dX grid leaves >= 15 % of its "
+                              "CU-rounds idle (encoder.WGRAD_STREAM = auto; not on ViT-B/16 at batch 256); the per-launch timing leg runs on one stream",
                    "residual_stream": "fp32", "gemm_operands": "bf16", "accumulate": "fp32",
                    "timing": f"{args.warmup} warm-up + {args.steps} timed steps, barrier + synchronize on both sides; "
                              "ms_per_step_median = median of per-step HIP-event spans on the compute stream"},

@@ -125,6 +125,25 @@ int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
                      float* dbias, float dbias_beta,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* All weight gradients of a layer in ONE launch (ABI 11): up to 4 problems C_i[M_i,N_i] = beta_i * C_i + sum_t A_i[t,:]^T B_i[t,:]
+ * over the same T token rows (dWqkv, dWo, dW1, dW2 of an encoder block: utils.py:693-706, simple_vit.py:39-41,61-62), optional
+ * dbias_i[m] = dbias_beta_i * dbias_i[m] + sum_t A_i[t,m].  Stream-K: the 256 x 256 tiles of all problems x the K-steps of 64
+ * token rows are split evenly over one workgroup per CU; partial tiles go through `workspace` and are added in a fixed order
+ * (deterministic per CU count).  Same operand rules as nrv_gemm_tn_bf16 (no row remap).  `problems` is a HOST array, read
+ * during the call.  nrv_gemm_tn_grouped_workspace returns 0 for a group the kernel does not take (T < 512 token rows, fewer than
+ * 8 K-steps of work per CU, more than 2 tiles per CU): issue nrv_gemm_tn_bf16 per problem then. */
+typedef struct nrv_tn_problem {
+    const void* A; int64_t lda;          /* bf16 [T, M] */
+    const void* B; int64_t ldb;          /* bf16 [T, N] */
+    float* C; int64_t ldc;               /* fp32 [M, N] */
+    int64_t M, N;
+    float beta;                          /* 0 or 1 */
+    float* dbias; float dbias_beta;      /* optional fp32 [M]; beta 0 or 1 */
+} nrv_tn_problem;
+size_t nrv_gemm_tn_grouped_workspace(const nrv_tn_problem* problems, int nprob, int64_t T);
+int nrv_gemm_tn_grouped_bf16(const nrv_tn_problem* problems, int nprob, int64_t T,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* Column sum (bias gradient of nn.Linear's backward): out[n] = beta*out[n] + sum_t X[t,n].
  *   X bf16 [T,N] ld; N % 8 == 0.  workspace: nrv_colsum_workspace(T, N) bytes. */
 size_t nrv_colsum_workspace(int64_t T, int64_t N);

@@ -21,6 +21,14 @@ PATCH_P1P2C, PATCH_CP1P2 = 0, 1
 ABI_VERSION = 11
 ATTN_QKV_BLOCKED, ATTN_OUT_BLOCKED = 1, 2      # include/nrv.h: NRV_ATTN_*_BLOCKED
 
+
+
+class TnProblem(ctypes.Structure):
+    """include/nrv.h `nrv_tn_problem`: one weight gradient of a grouped launch."""
+    _fields_ = [("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64),
+                ("M", c_int64), ("N", c_int64), ("beta", c_float), ("dbias", c_void_p), ("dbias_beta", c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/nrv.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {
     "nrv_abi_version": (c_int, []),
@@ -39,6 +47,8 @@ SIGNATURES = {
     "nrv_gemm_tn_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                  c_int64, c_int64, c_int64, c_float, c_int64, c_int64, c_int64,
                                  c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "nrv_gemm_tn_grouped_workspace": (c_size_t, [c_void_p, c_int, c_int64]),
+    "nrv_gemm_tn_grouped_bf16": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_size_t, c_void_p]),
     "nrv_colsum_workspace": (c_size_t, [c_int64, c_int64]),
     "nrv_colsum_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
     "nrv_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),

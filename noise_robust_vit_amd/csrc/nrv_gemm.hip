@@ -1122,10 +1122,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(const GemmTNParam
 // swizzled by the row), B half image = [64 token rows][the 32 columns of half h of the four wave columns]; both are read
 // with ds_read_b64_tr_b16.  Host: no row remap, every split has at least three K-steps.
 // ---------------------------------------------------------------------------------------------
+// one unit of TN work: the 256 x 256 output tile (m0, n0) of C = A^T B over the token rows [t_begin, t_begin + trem), nk K-steps
+// (the last one may be partial), written as an fp32 tile to `out` (leading dimension out_ld: a slab of the whole matrix, or a
+// dense tile slot) and, with bias_out, the column sums of A of those rows to bias_out[0 .. 255] (first column tile only)
+struct TnSeg {
+    const bf16_t* A;
+    const bf16_t* B;
+    long long lda, ldb;
+    int M, N, m0, n0;
+    int t_begin, trem, nk;
+    float* out;                      // element (m0, n0) of the destination
+    long long out_ld;
+    float* bias_out;                 // element m0 of the destination, or nullptr
+};
+
 template <typename C>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNParams p) {
+__device__ __forceinline__ void tn8_segment(const TnSeg& sg, char* smem) {
     static_assert(C::WM == 2 && C::WN == 4 && C::MI % 2 == 0, "2 x 4 waves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MH = C::MI / 2;
     constexpr int RAH = C::TBM, RBH = C::TBN;                 // bytes per token row of a half image (TBM / 2 columns x 2 bytes)
     constexpr int AH = BK * RAH, BH = BK * RBH, STG = 2 * AH + 2 * BH;
@@ -1137,21 +1150,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     const int wr = wave >> 2, wc = wave & 3;
     NRV_WACC_VARS;                   // hooks: empty in the product (csrc/nrv_dev.hpp)
 
-    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = id / p.tiles_mn;
-    const int tile = id - split * p.tiles_mn;
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * C::TBM, n0 = tn * C::TBN;
-    const int M = p.e.M, N = p.e.N;
-    const int nk = p.kt_q + (split < p.kt_r ? 1 : 0);        // >= 3 (host)
-    const int t_begin = (split * p.kt_q + (split < p.kt_r ? split : p.kt_r)) * BK;
-    int t_end = t_begin + nk * BK;
-    if (t_end > p.T) t_end = p.T;
-    const int trem = t_end - t_begin;                         // > 64 (nk - 1) >= 128
+    const int m0 = sg.m0, n0 = sg.n0;
+    const int M = sg.M, N = sg.N;
+    const int nk = sg.nk;                                     // >= 3 (host)
+    const int t_begin = sg.t_begin;
+    const int trem = sg.trem;                                 // > 64 (nk - 1) >= 128
+    struct { const bf16_t* A; const bf16_t* B; long long lda, ldb; } p = {sg.A, sg.B, sg.lda, sg.ldb};
 
     const int acols = M - m0 < C::TBM ? M - m0 : C::TBM, bcols = N - n0 < C::TBN ? N - n0 : C::TBN;
-    // records end with the last valid column of the split's last token row: rows >= t_end read as zero, the K position is
-    // the scalar soffset (< the records for every K-step of the split)
+    // records end with the last valid column of the segment's last token row: rows beyond it read as zero, the K position is
+    // the scalar soffset (< the records for every K-step of the segment)
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long long)t_begin * p.lda + m0, ((unsigned long long)(trem - 1) * p.lda + acols) * 2ull);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long long)t_begin * p.ldb + n0, ((unsigned long long)(trem - 1) * p.ldb + bcols) * 2ull);
 
@@ -1231,7 +1239,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     // fused bias gradient db[m] = sum_t A[t, m] = (ones . A) on the MFMA, first column tile only; wave column wc takes the row
     // blocks 2 wc, 2 wc + 1 of its wave row: half wc >> 1, fragments (wc & 1) * MH / 2 + {0, 1}
     static_assert(MH == 4, "bias-gradient block assignment");
-    const bool do_bias = p.bias_ws != nullptr && tn == 0;
+    const bool do_bias = sg.bias_out != nullptr;
     const u32x4_t ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
     f32x4_t accb[2];
@@ -1363,15 +1371,166 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
     if (do_bias && lane < 16) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wr * (C::MI * 16) + (2 * wc + j) * 16 + lane;
-            if (m < M) p.bias_ws[(long long)split * M + m] = accb[j][0];
+            const int ml = wr * (C::MI * 16) + (2 * wc + j) * 16 + lane;
+            if (m0 + ml < M) sg.bias_out[ml] = accb[j][0];
         }
     }
-    EpiParams e = p.e;
-    e.C = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride;
+    // the destination is addressed relative to the tile: rows / columns beyond the matrix are dropped by the range check
+    EpiParams e;
+    e.C = sg.out; e.bias = nullptr; e.aux = nullptr; e.aux_out = nullptr;
+    e.ldc = sg.out_ld; e.ld_aux = 0; e.ld_aux_out = 0;
+    e.M = acols; e.N = bcols; e.aux_row_mod = 0; e.out_group = 0; e.out_group_stride = 0; e.out_row_offset = 0;
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));            // keeps the epilogue's per-lane address arithmetic below the K loop
-    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, reinterpret_cast<float*>(smem + wave * EPI_PATCH_BYTES), e, m0 + wr * (C::MI * 16), n0 + wc * 64, lane_e);
+    epilogue_lin<NRV_EPI_NONE, true, true, C::MI>(acc, reinterpret_cast<float*>(smem + wave * EPI_PATCH_BYTES), e, wr * (C::MI * 16), wc * 64, lane_e);
+}
+
+template <typename C>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / p.tiles_mn;
+    const int tile = id - split * p.tiles_mn;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    TnSeg sg;
+    sg.A = p.A; sg.B = p.B; sg.lda = p.lda; sg.ldb = p.ldb;
+    sg.M = p.e.M; sg.N = p.e.N; sg.m0 = tm * C::TBM; sg.n0 = tn * C::TBN;
+    sg.nk = p.kt_q + (split < p.kt_r ? 1 : 0);               // >= 3 (host)
+    sg.t_begin = (split * p.kt_q + (split < p.kt_r ? split : p.kt_r)) * BK;
+    int t_end = sg.t_begin + sg.nk * BK;
+    if (t_end > p.T) t_end = p.T;
+    sg.trem = t_end - sg.t_begin;
+    sg.out = reinterpret_cast<float*>(p.e.C) + (long long)split * p.slab_stride + (long long)sg.m0 * p.e.ldc + sg.n0;
+    sg.out_ld = p.e.ldc;
+    sg.bias_out = (p.bias_ws != nullptr && tn == 0) ? p.bias_ws + (long long)split * p.e.M + sg.m0 : nullptr;
+    tn8_segment<C>(sg, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped stream-K TN GEMM: ALL weight gradients of a layer in one launch.  The 256 x 256 output tiles of up to four problems
+// (same token count T) are numbered consecutively; the work is the flattened space (tile, K-step) of ntiles * nk units, and
+// workgroup w of W = one per CU takes the units [bound(w), bound(w + 1)) -- an equal share, whatever the tile count -- as at most
+// TNG_SEGS segments, one per tile it touches.  Every segment writes its partial tile to a dense slot
+// (slot = TNG_SEGS * w + index of the tile within the workgroup's range) and tng_fixup_kernel adds the slots of a tile in
+// workgroup order into C: deterministic, no atomics, no waiting on other workgroups.
+// Against one split-K launch per gradient (nrv_gemm_tn_bf16): the 256 CUs are full whatever the shapes (a 768 x 768 gradient has
+// 9 tiles, ViT-S's 384 x 384 has 4 with 44 % padding), a workgroup's K loop is T * ntiles / (64 W) steps long instead of
+// T / (64 splits) (ViT-S: 117 instead of 12-37: prologue, epilogue and the 256-KiB partial store are paid once or twice per
+// workgroup and LAYER instead of four times), and the partial traffic is (W + ntiles) tiles per layer instead of 4 W.
+// bound(w) = floor(w * units / W), moved onto a tile boundary when it falls within 3 K-steps of one: every segment has the
+// >= 3 K-steps the phased loop needs (host: nk >= 8 and units / W >= 8).
+// ---------------------------------------------------------------------------------------------
+constexpr int TNG_MAX = 4;                  // problems per launch
+constexpr int TNG_SEGS = 3;                 // tile slots per workgroup (host: units / W >= nk / 2 keeps a range within 3 tiles)
+
+struct TngProblem {
+    const bf16_t* A;
+    const bf16_t* B;
+    float* C;
+    float* dbias;                           // or nullptr
+    long long lda, ldb, ldc;
+    int M, N;
+    int tiles_n, tile0;                     // column tiles; global index of the problem's first tile
+    float beta, dbias_beta;
+};
+
+struct GemmTNGParams {
+    TngProblem pr[TNG_MAX];
+    int nprob, ntiles, nk, T, W;
+    long long units;                        // ntiles * nk
+    float* slots;                           // [TNG_SEGS * W][256 * 256] partial tiles
+    float* bias_slots;                      // [TNG_SEGS * W][256] partial column sums
+};
+
+__host__ __device__ __forceinline__ long long tng_bound(long long w, long long units, int W, int nk) {
+    long long b = w * units / W;
+    const int r = (int)(b % nk);
+    if (r < 3) b -= r;
+    else if (nk - r < 3) b += nk - r;
+    return b;
+}
+
+__device__ __forceinline__ int tng_problem_of(const GemmTNGParams& p, int tile) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < TNG_MAX; ++i)
+        if (i < p.nprob && tile >= p.pr[i].tile0) pi = i;
+    return pi;
+}
+
+template <typename C>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tng_kernel(const GemmTNGParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long b0 = tng_bound(blockIdx.x, p.units, p.W, p.nk), b1 = tng_bound(blockIdx.x + 1, p.units, p.W, p.nk);
+    const int first_tile = (int)(b0 / p.nk);
+    for (long long u = b0; u < b1;) {                            // workgroup-uniform
+        const int tile = (int)(u / p.nk);
+        const int k0 = (int)(u - (long long)tile * p.nk);
+        const long long tile_end = (long long)(tile + 1) * p.nk;
+        const int k1 = (int)((b1 < tile_end ? b1 : tile_end) - (long long)tile * p.nk);
+        const int pi = tng_problem_of(p, tile);
+        const TngProblem& q = p.pr[pi];
+        const int lt = tile - q.tile0;
+        const int tm = lt / q.tiles_n, tn = lt - tm * q.tiles_n;
+        const int slot = TNG_SEGS * blockIdx.x + (tile - first_tile);
+        TnSeg sg;
+        sg.A = q.A; sg.B = q.B; sg.lda = q.lda; sg.ldb = q.ldb;
+        sg.M = q.M; sg.N = q.N; sg.m0 = tm * C::TBM; sg.n0 = tn * C::TBN;
+        sg.nk = k1 - k0;
+        sg.t_begin = k0 * BK;
+        const int t_end = k1 * BK < p.T ? k1 * BK : p.T;
+        sg.trem = t_end - sg.t_begin;
+        sg.out = p.slots + (long long)slot * (C::TBM * C::TBN);
+        sg.out_ld = C::TBN;
+        sg.bias_out = (q.dbias != nullptr && tn == 0) ? p.bias_slots + (long long)slot * C::TBM : nullptr;
+        tn8_segment<C>(sg, smem);
+        u = (long long)tile * p.nk + k1;
+        __syncthreads();                                         // the epilogue's LDS patches are the next segment's stage buffers
+    }
+}
+
+// C tile = beta * C + the tile's partial slots in workgroup order.  Block = 4 waves on 64 consecutive 16-byte chunks of one tile;
+// wave g sums the contributors g, g + 4, ..., the four sums meet in LDS and are added in the fixed order ((p0 + p1) + (p2 + p3)).
+// The first block of a first-column tile also reduces the bias slots.
+__global__ __launch_bounds__(256) void tng_fixup_kernel(const GemmTNGParams p) {
+    __shared__ f32x4_t part[4][64];
+    constexpr int TILE = 256, CHUNKS = TILE * TILE / 4, BLOCKS_PER_TILE = CHUNKS / 64;
+    const int tile = blockIdx.x / BLOCKS_PER_TILE, blk = blockIdx.x - tile * BLOCKS_PER_TILE;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const TngProblem& q = p.pr[tng_problem_of(p, tile)];
+    const int lt = tile - q.tile0;
+    const int tm = lt / q.tiles_n, tn = lt - tm * q.tiles_n;
+    // contributors: the workgroups whose unit range meets [tile * nk, (tile + 1) * nk)
+    const long long u0 = (long long)tile * p.nk, u1 = u0 + p.nk;
+    int w0 = (int)(u0 * p.W / p.units);
+    while (w0 > 0 && tng_bound(w0, p.units, p.W, p.nk) > u0) --w0;
+    while (w0 + 1 < p.W && tng_bound(w0 + 1, p.units, p.W, p.nk) <= u0) ++w0;
+    int w1 = w0;
+    while (w1 + 1 < p.W && tng_bound(w1 + 1, p.units, p.W, p.nk) < u1) ++w1;
+    auto slot_of = [&](int w) { return (long long)TNG_SEGS * w + (tile - (int)(tng_bound(w, p.units, p.W, p.nk) / p.nk)); };
+
+    const int c = blk * 64 + lane;                               // chunk of the tile: row c / 64, columns 4 (c % 64) ..
+    const int row = c >> 6, col = (c & 63) << 2;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int w = w0 + g; w <= w1; w += 4)
+        s += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p.slots + slot_of(w) * (TILE * TILE) + row * TILE + col));
+    part[g][lane] = s;
+    __syncthreads();
+    const int m = tm * TILE + row, n = tn * TILE + col;
+    if (g == 0 && m < q.M && n < q.N) {                          // N % 4 == 0 (host): a chunk is inside or outside
+        f32x4_t t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float* dst = q.C + (long long)m * q.ldc + n;
+        if (q.beta != 0.f) t += *reinterpret_cast<const f32x4_t*>(dst) * q.beta;
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(dst));
+    }
+    if (blk == 0 && tn == 0 && q.dbias != nullptr) {
+        const int mm = tm * TILE + threadIdx.x;
+        if (mm < q.M) {
+            float b = 0.f;
+            for (int w = w0; w <= w1; ++w) b += p.bias_slots[slot_of(w) * TILE + threadIdx.x];
+            q.dbias[mm] = q.dbias_beta != 0.f ? q.dbias_beta * q.dbias[mm] + b : b;
+        }
+    }
 }
 
 // C = beta * C + sum_s slab[s].  A block of 4 waves owns 64 consecutive 16-byte chunks of C; wave g sums the slabs
@@ -1680,5 +1839,71 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
                            (int)M, (int)N, beta, static_cast<const float*>(p.bias_ws), dbias, dbias_beta);
         NRV_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+// ---- grouped stream-K form: all weight gradients of a layer in one launch (gemm_tng_kernel) ----------------------------------
+namespace {
+// launch plan of a group, or W == 0 when the grouped kernel does not take it (the caller then issues nrv_gemm_tn_bf16 per problem)
+struct TngPlan { int W, nk, ntiles; long long units; };
+TngPlan tng_plan(const nrv_tn_problem* pr, int n, int64_t T) {
+    TngPlan pl{0, 0, 0, 0};
+    if (!pr || n < 1 || n > TNG_MAX || T <= 0 || T > 0x7fffff00ll) return pl;
+    long long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (pr[i].M <= 0 || pr[i].N <= 0 || pr[i].M > 0x7fffff00ll || pr[i].N > 0x7fffff00ll) return pl;
+        tiles += nrv_cdiv(pr[i].M, 256) * nrv_cdiv(pr[i].N, 256);
+    }
+    const int W = device_cus();
+    const long long nk = nrv_cdiv(T, BK);
+    // every segment needs >= 3 K-steps: boundaries snap to tile boundaries within 3 K-steps, so a range must be longer than that
+    // (>= 8) and a tile much longer (nk >= 8); a range may span at most TNG_SEGS tiles (tiles <= 2 W)
+    if (nk < 8 || tiles * nk / W < 8 || tiles > 2ll * W || tiles * nk > 0x3fffffffll) return pl;
+    pl.W = W; pl.nk = (int)nk; pl.ntiles = (int)tiles; pl.units = tiles * nk;
+    return pl;
+}
+}  // namespace
+
+extern "C" size_t nrv_gemm_tn_grouped_workspace(const nrv_tn_problem* problems, int nprob, int64_t T) {
+    const TngPlan pl = tng_plan(problems, nprob, T);
+    if (pl.W == 0) return 0;
+    return (size_t)TNG_SEGS * (size_t)pl.W * (256 * 256 + 256) * 4;
+}
+
+extern "C" int nrv_gemm_tn_grouped_bf16(const nrv_tn_problem* problems, int nprob, int64_t T,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!problems || !workspace) return NRV_ERR_NULL;
+    const TngPlan pl = tng_plan(problems, nprob, T);
+    if (pl.W == 0) return NRV_ERR_SHAPE;
+    if (workspace_bytes < (size_t)TNG_SEGS * (size_t)pl.W * (256 * 256 + 256) * 4) return NRV_ERR_WORKSPACE;
+    if (!nrv_aligned16(workspace)) return NRV_ERR_ALIGN;
+    GemmTNGParams p;
+    int tile0 = 0;
+    for (int i = 0; i < TNG_MAX; ++i) {
+        TngProblem& q = p.pr[i];
+        if (i >= nprob) { q = p.pr[0]; q.tile0 = 0x7fffffff; continue; }
+        const nrv_tn_problem& s = problems[i];
+        if (!s.A || !s.B || !s.C) return NRV_ERR_NULL;
+        if ((s.M & 7) || (s.N & 7) || (s.lda & 7) || (s.ldb & 7) || s.lda < s.M || s.ldb < s.N || s.ldc < s.N || (s.ldc & 3)) return NRV_ERR_SHAPE;
+        if (!nrv_aligned16(s.A) || !nrv_aligned16(s.B) || !nrv_aligned16(s.C)) return NRV_ERR_ALIGN;
+        if ((s.beta != 0.f && s.beta != 1.f) || (s.dbias && s.dbias_beta != 0.f && s.dbias_beta != 1.f)) return NRV_ERR_SHAPE;
+        // a segment's operand window (at most one tile's token range) must stay below 2 GiB of byte offset
+        if ((long long)pl.nk * BK * s.lda * 2 >= 0x7fffffffll || (long long)pl.nk * BK * s.ldb * 2 >= 0x7fffffffll) return NRV_ERR_SHAPE;
+        q.A = static_cast<const bf16_t*>(s.A); q.B = static_cast<const bf16_t*>(s.B); q.C = s.C; q.dbias = s.dbias;
+        q.lda = s.lda; q.ldb = s.ldb; q.ldc = s.ldc; q.M = (int)s.M; q.N = (int)s.N;
+        q.tiles_n = (int)nrv_cdiv(s.N, 256); q.tile0 = tile0;
+        q.beta = s.beta; q.dbias_beta = s.dbias_beta;
+        tile0 += (int)(nrv_cdiv(s.M, 256) * nrv_cdiv(s.N, 256));
+    }
+    p.nprob = nprob; p.ntiles = pl.ntiles; p.nk = pl.nk; p.T = (int)T; p.W = pl.W; p.units = pl.units;
+    p.slots = static_cast<float*>(workspace);
+    p.bias_slots = p.slots + (size_t)TNG_SEGS * pl.W * 256 * 256;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static int attr = set_lds(gemm_tng_kernel<TnCfg256>, TnCfg256::LDS);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL(gemm_tng_kernel<TnCfg256>, dim3(pl.W), dim3(GEMM_THREADS), TnCfg256::LDS, s, p);
+    NRV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tng_fixup_kernel, dim3(pl.ntiles * (256 * 256 / 4 / 64)), dim3(256), 0, s, p);
+    NRV_CHECK_LAUNCH();
     return 0;
 }

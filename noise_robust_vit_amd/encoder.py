@@ -199,44 +199,64 @@ def wgrad_join() -> None:
         _WGRAD_KEEP.clear()
 
 
+# Weight gradients are QUEUED while a layer is differentiated and issued together when it is done (`wgrad_flush`): the four of an
+# encoder block (dWqkv, dWo, dW1, dW2 and their bias gradients) are ONE stream-K launch (kernels.gemm_tn_grouped) that fills every
+# CU whatever the matrices' tile counts and pays prologue, epilogue and partial-tile traffic once per layer instead of once per
+# gradient (round 4; before: one split-K launch + one slab reduction per gradient).
+_PENDING: list = []
+
+
 def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
-    """Weight and bias gradient of y = x W^T + b in ONE kernel: dW = dy^T x on the MFMA, db = colsum(dy) fused.
-    With a gradient sink (results go to persistent buffers nobody reads before `wgrad_join`) the launch may go to the side stream."""
-    if meta.sink is not None and _wgrad_on_side(dy16, x16):
-        side = _wgrad_side(dy16.device)
-        side.wait_stream(torch.cuda.current_stream(dy16.device))
-        _WGRAD_KEEP.append((dy16, x16))          # alive until the join: the allocator must not hand them out while the side stream reads
-        with torch.cuda.stream(side):
-            return _dw_db_run(meta, dy16, x16, w, b)
-    return _dw_db_run(meta, dy16, x16, w, b)
-
-
-def _dw_db_run(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
+    """Queue the weight and bias gradient of y = x W^T + b (dW = dy^T x on the MFMA, db = colsum(dy) fused into the same kernel).
+    Returns (dW, db) as the tensors the launch of `wgrad_flush` will fill: the sink's flat-buffer views, or fresh ones."""
     parts = getattr(w, "_nrv_parts", None)
     if parts is not None and meta.sink is not None:
-        # w stacks the rows of several parameters ([to_q; to_kv]): one TN GEMM per parameter on the matching column block of
-        # dy, straight into that parameter's slot of the sink (no fused gradient, no split / accumulate pass)
+        # w stacks the rows of several parameters ([to_q; to_kv]): straight into their slots of the sink -- one problem when the
+        # slots are adjacent (GradReducer + grad_groups), else one per parameter on the matching column block of dy
         if b is not None:
             raise NrvError("a fused projection carries no bias")
         block = meta.sink.target_block([pp for pp, _, _ in parts]) if hasattr(meta.sink, "target_block") else None
-        if block is not None:                    # the parameters' slots are adjacent (GradReducer + grad_groups): one GEMM
-            K.gemm_tn(dy16, x16, out=block[0], beta=block[1])
+        if block is not None:
+            _PENDING.append(dict(A=dy16, B=x16, out=block[0], beta=block[1]))
             return None, None
         for pp, r0, r1 in parts:
             tw, bw = meta.sink.target(pp)
-            K.gemm_tn(dy16[:, r0:r1], x16, out=tw, beta=bw)
+            _PENDING.append(dict(A=dy16[:, r0:r1], B=x16, out=tw, beta=bw))
         return None, None
     tw, bw = _grad_target(meta, w)
     tb, bb = _grad_target(meta, b) if b is not None else (None, 0.0)
+    M, N = dy16.shape[1], x16.shape[1]
+    out = tw if tw is not None else torch.empty(M, N, dtype=torch.float32, device=dy16.device)
+    dbias = None if b is None else (tb if tb is not None else torch.empty(M, dtype=torch.float32, device=dy16.device))
+    _PENDING.append(dict(A=dy16, B=x16, out=out, beta=bw if tw is not None else 0.0, dbias=dbias, dbias_beta=bb if tb is not None else 0.0))
+    return out, dbias
 
-    def run():
-        if b is None:
-            return K.gemm_tn(dy16, x16, out=tw, beta=bw), None
-        if tb is None:
-            return K.gemm_tn(dy16, x16, out=tw, beta=bw, want_dbias=True)
-        return K.gemm_tn(dy16, x16, out=tw, beta=bw, dbias=tb, dbias_beta=bb)
 
-    return run()
+def wgrad_flush(meta: BlockMeta) -> None:
+    """Issue the queued weight gradients (groups of up to 4 with the same token count).  With a gradient sink (results go to
+    persistent buffers nobody reads before `wgrad_join`) the launch may go to the side stream, beside the next layer's dX chain."""
+    if not _PENDING:
+        return
+    probs = list(_PENDING)
+    _PENDING.clear()
+    groups, cur = [], []
+    for q in probs:
+        if cur and (len(cur) == 4 or q["A"].shape[0] != cur[0]["A"].shape[0]):
+            groups.append(cur)
+            cur = []
+        cur.append(q)
+    groups.append(cur)
+    dy16, x16 = probs[0]["A"], probs[0]["B"]
+    if meta.sink is not None and _wgrad_on_side(dy16, x16):
+        side = _wgrad_side(dy16.device)
+        side.wait_stream(torch.cuda.current_stream(dy16.device))
+        _WGRAD_KEEP.append(tuple(t for q in probs for t in (q["A"], q["B"])))     # alive until the join
+        with torch.cuda.stream(side):
+            for g in groups:
+                K.gemm_tn_grouped(g)
+        return
+    for g in groups:
+        K.gemm_tn_grouped(g)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -391,6 +411,7 @@ def _as_stream(x: Tensor):
 
 def _mask_sink_grads(meta: BlockMeta, grads: List[Optional[Tensor]]) -> List[Optional[Tensor]]:
     """With a sink attached the kernels already wrote into the sink's buffers: hand autograd nothing."""
+    wgrad_flush(meta)                  # autograd receives the tensors of `grads`: the queued launches must have been issued
     if meta.sink is None:
         return grads
     wgrad_join()
@@ -425,16 +446,24 @@ class EncoderStackFn(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None] * len(params)
         # the residual-stream gradient travels between the halves in fp32 (it is the sum of 2 x depth branch gradients; a bf16
         # stream was measured 1.9 % faster in round 1 and rejected: it rounds the running sum to 8 bits after every add)
+        done = None                                          # layer whose weight gradients were issued, not yet declared final
         for i in reversed(range(depth)):
             p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             sa, sm = saved[i]
             d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True)
             d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0)
             grads[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = ga + gm
+            # the previous layer's grouped weight-gradient launch (side stream: it ran beside this layer's dX chain) is joined
+            # and its parameters declared final; then this layer's four gradients go out as one launch
             wgrad_join()
-            saved[i] = None                                  # free this block's activations early
-            if meta.sink is not None:
-                meta.sink.layer_done(i, sink_params(p))
+            if done is not None and meta.sink is not None:
+                meta.sink.layer_done(done[0], done[1])
+            wgrad_flush(meta)
+            done = (i, sink_params(p))
+            saved[i] = None                                  # free this block's activations early (queued operands are held by the launch)
+        wgrad_join()
+        if done is not None and meta.sink is not None:
+            meta.sink.layer_done(done[0], done[1])
         grads = _mask_sink_grads(meta, grads)
         return (d32.reshape(B, N, D), None, *grads)
 
@@ -597,13 +626,19 @@ class LinearFn(torch.autograd.Function):
         return dx.reshape(shp), dw, db
 
 
+def _flat_token_index(index: Tensor, n: int) -> Tensor:
+    B = index.shape[0]
+    return (index + torch.arange(B, device=index.device)[:, None] * n).reshape(-1).contiguous()
+
+
 class GatherTokensFn(torch.autograd.Function):
-    """tokens[b, index[b, :]] (MAE keeps a random 25 % of the tokens, mae.py:75-76); backward scatters rows back."""
+    """tokens[b, index[b, :]] (MAE keeps a random 25 % of the tokens, mae.py:75-76; reads the decoder's output at the masked
+    positions, mae.py:112); backward scatters rows back.  Bounds-checked row kernels, no library sort in either direction."""
 
     @staticmethod
     def forward(ctx, tokens, index):
         B, n, D = tokens.shape
-        flat = (index + torch.arange(B, device=index.device)[:, None] * n).reshape(-1).contiguous()
+        flat = _flat_token_index(index, n)
         out = K.gather_rows(tokens.detach().to(torch.float32).contiguous().reshape(B * n, D), flat)
         ctx.save_for_backward(flat)
         ctx.shape = (B, n, D, index.shape[1])
@@ -615,6 +650,28 @@ class GatherTokensFn(torch.autograd.Function):
         B, n, D, k = ctx.shape
         d = K.scatter_rows(dy.to(torch.float32).contiguous().reshape(B * k, D), flat, B * n)
         return d.reshape(B, n, D), None
+
+
+class ScatterTokensFn(torch.autograd.Function):
+    """out[b, index[b, j]] = rows[b, j], zeros elsewhere (MAE re-assembles the full-length decoder sequence from the kept tokens,
+    mae.py:103-107; indices unique per sample); backward gathers.  The counterpart of GatherTokensFn: torch's index_put / Embedding
+    backward would bring library sort kernels into the step (and into its HIP graph)."""
+
+    @staticmethod
+    def forward(ctx, rows, index, n: int):
+        B, k, D = rows.shape
+        flat = _flat_token_index(index, n)
+        out = K.scatter_rows(rows.detach().to(torch.float32).contiguous().reshape(B * k, D), flat, B * n)
+        ctx.save_for_backward(flat)
+        ctx.shape = (B, n, D, k)
+        return out.reshape(B, n, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (flat,) = ctx.saved_tensors
+        B, n, D, k = ctx.shape
+        d = K.gather_rows(dy.to(torch.float32).contiguous().reshape(B * n, D), flat)
+        return d.reshape(B, k, D), None, None
 
 
 def flat_layer_params(layers: Sequence[Sequence[Optional[Tensor]]]) -> List[Optional[Tensor]]:

@@ -6,6 +6,7 @@ arithmetic result comes from a kernel in libnrv_hip.so.  All tensors must live o
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -242,6 +243,55 @@ def gemm_tn(A: Tensor, B: Tensor, *, out: Optional[Tensor] = None, beta: float =
     if dbias is not None:
         return out, dbias
     return out
+
+
+def gemm_tn_grouped(problems) -> list:
+    """ALL weight gradients of a layer in one stream-K launch (include/nrv.h nrv_gemm_tn_grouped_bf16).  `problems`: up to 4
+    dicts {A: dy bf16 [T, M], B: x bf16 [T, N], out: fp32 [M, N] | None, beta, dbias: fp32 [M] | None | True (allocate),
+    dbias_beta}; all with the same T.  Returns [(out, dbias | None)].  Groups the kernel does not take (tiny T) run as
+    separate `gemm_tn` calls -- the same arithmetic per gradient, another summation order."""
+    if not problems:
+        return []
+    lib = _lib.load()
+    T = problems[0]["A"].shape[0]
+    arr = (_lib.TnProblem * len(problems))()
+    outs = []
+    for i, q in enumerate(problems):
+        A, B = q["A"], q["B"]
+        _bf16(A, "A"); _bf16(B, "B")
+        Ta, M, lda = _rows2d(A, "A")
+        Tb, N, ldb = _rows2d(B, "B")
+        if Ta != T or Tb != T:
+            raise NrvError(f"gemm_tn_grouped: problem {i} has {Ta} / {Tb} token rows, the group has {T}")
+        out, beta = q.get("out"), float(q.get("beta", 0.0))
+        if out is None:
+            out, beta = torch.empty(M, N, dtype=torch.float32, device=A.device), 0.0
+        _f32(out, "out")
+        if out.shape[0] < M or out.shape[1] < N:
+            raise NrvError(f"gemm_tn_grouped: out of problem {i} is {tuple(out.shape)}, the gradient is [{M}, {N}]")
+        _, _, ldc = _rows2d(out, "out")
+        dbias, dbb = q.get("dbias"), float(q.get("dbias_beta", 0.0))
+        if dbias is True:
+            dbias, dbb = torch.empty(M, dtype=torch.float32, device=A.device), 0.0
+        if dbias is not None:
+            _f32(dbias, "dbias")
+            if dbias.numel() < M:
+                raise NrvError("gemm_tn_grouped: dbias is shorter than the gradient's rows")
+        arr[i] = _lib.TnProblem(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, beta, _ptr(dbias), dbb)
+        outs.append((out, dbias))
+    nbytes = int(lib.nrv_gemm_tn_grouped_workspace(ctypes.addressof(arr), len(problems), T)) if len(problems) <= 4 else 0
+    if nbytes == 0:                                   # not taken by the grouped kernel: one split-K launch per gradient
+        for q, (out, dbias) in zip(problems, outs):
+            gemm_tn(q["A"], q["B"], out=out, beta=float(q.get("beta", 0.0)) if q.get("out") is not None else 0.0,
+                    dbias=dbias, dbias_beta=float(q.get("dbias_beta", 0.0)) if q.get("dbias") not in (None, True) else 0.0)
+        return outs
+    ws = _workspace(nbytes, problems[0]["A"].device)
+    flops = sum(2.0 * T * q["A"].shape[1] * q["B"].shape[1] for q in problems)
+    nb = sum(2 * T * (q["A"].shape[1] + q["B"].shape[1]) + 4 * q["A"].shape[1] * q["B"].shape[1] for q in problems)
+    _run("gemm_tn", flops, nb,
+         lambda: lib.nrv_gemm_tn_grouped_bf16(ctypes.addressof(arr), len(problems), T, ws.data_ptr(), ws.numel(), _stream()),
+         "nrv_gemm_tn_grouped_bf16")
+    return outs
 
 
 def colsum(X: Tensor, *, out: Optional[Tensor] = None, beta: float = 0.0) -> Tensor:

@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from ._lib import PATCH_P1P2C
-from .encoder import GatherTokensFn, LinearFn, PatchEmbedFn
+from .encoder import GatherTokensFn, LinearFn, PatchEmbedFn, ScatterTokensFn
 from .lucid_vit import Transformer
 
 
@@ -62,14 +62,16 @@ class MAE(nn.Module):
     def _project(self, layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
         return LinearFn.apply(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else x
 
-    def _decoder_input(self, kept_tokens, kept_idx, drop_idx, rows, n):
-        """Full-length decoder sequence: projected encoder outputs at the kept positions, the mask token elsewhere,
-        decoder positions added to both (mae.py:92-107)."""
-        b, n_drop = drop_idx.shape
-        seq = kept_tokens.new_zeros(b, n, self.decoder_dim)
-        seq[rows, kept_idx] = kept_tokens + self.decoder_pos_emb(kept_idx)
-        seq[rows, drop_idx] = self.mask_token.expand(b, n_drop, self.decoder_dim) + self.decoder_pos_emb(drop_idx)
-        return seq
+    def _decoder_input(self, kept_tokens, kept_idx, n):
+        """Full-length decoder sequence: projected encoder outputs at the kept positions, the mask token elsewhere, decoder
+        positions added to both (mae.py:92-107).  Every position is either kept or masked, so `decoder_pos_emb(kept_idx)` and
+        `decoder_pos_emb(masked_idx)` together are the table's first n rows in place: one broadcast add instead of two Embedding
+        lookups whose backward sorts indices, and the kept rows go through the bounds-checked scatter kernel instead of index_put."""
+        b = kept_tokens.shape[0]
+        seq = ScatterTokensFn.apply(kept_tokens, kept_idx, n)                       # zeros at the masked positions
+        masked = torch.ones(b, n, 1, device=kept_tokens.device, dtype=seq.dtype)
+        masked.scatter_(1, kept_idx.unsqueeze(-1), 0.0)                            # 1 where the mask token goes (no gradient)
+        return seq + masked * self.mask_token + self.decoder_pos_emb.weight[:n]
 
     # -- forward ----------------------------------------------------------------------------------------------------
     def forward(self, img, rand_indices=None):
@@ -88,6 +90,6 @@ class MAE(nn.Module):
 
         kept = GatherTokensFn.apply(self._embed_all(img, n), kept_idx)              # [b, n - n_drop, d]
         encoded = self.encoder.transformer(kept)                                    # the hot loop, 49 tokens for ViT-B/16
-        decoded = self.decoder(self._decoder_input(self._project(self.enc_to_dec, encoded), kept_idx, drop_idx, rows, n))
-        prediction = self._project(self.to_pixels, decoded[rows, drop_idx])
+        decoded = self.decoder(self._decoder_input(self._project(self.enc_to_dec, encoded), kept_idx, n))
+        prediction = self._project(self.to_pixels, GatherTokensFn.apply(decoded, drop_idx))
         return torch.nn.functional.mse_loss(prediction, patches[rows, drop_idx])

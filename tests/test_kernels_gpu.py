@@ -318,6 +318,68 @@ def test_gemm_tn(dev, T, M, N):
     assert rel_err(db2, 2 * A.float().sum(0)) < 1e-5 * math.sqrt(T)
 
 
+# grouped stream-K form: all weight gradients of a layer in one launch.  (T, [(M, N, bias)]): the ViT-B/16 layer at batch 256
+# (108 tiles on 256 workgroups), the ViT-S layer (38 tiles, 384-wide matrices: tile tails in M and N), token counts that are no
+# multiple of 64 (partial last K-step), a single problem, and a group too small for the kernel (separate split-K launches)
+TNG_CASES = {
+    "vit_b_layer": (50432, [(2304, 768, True), (768, 768, True), (3072, 768, True), (768, 3072, True)]),
+    "vit_s_layer_t4k": (4096, [(1152, 384, True), (384, 384, False), (1536, 384, True), (384, 1536, True)]),
+    "odd_t": (3001, [(768, 512, True), (264, 776, True)]),
+    "single": (8192, [(512, 512, False)]),
+    "mae_dec": (12544, [(1536, 512, False), (512, 512, True), (2048, 512, True), (512, 2048, True)]),
+    "too_small": (300, [(256, 256, True), (128, 64, False)]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(TNG_CASES))
+def test_gemm_tn_grouped(dev, case):
+    k = _k()
+    T, shapes = TNG_CASES[case]
+    probs, refs = [], []
+    for i, (M, N, bias) in enumerate(shapes):
+        A = rnd((T, M), dev, 140 + 2 * i)
+        B = rnd((T, N), dev, 141 + 2 * i)
+        probs.append(dict(A=A, B=B, dbias=True if bias else None))
+        refs.append((A.float().t() @ B.float(), A.float().sum(0)))
+    outs = k.gemm_tn_grouped(probs)
+    for (c, db), (rc, rdb), (M, N, bias) in zip(outs, refs, shapes):
+        assert c.shape == (M, N)
+        assert rel_err(c, rc) < 2e-5 * math.sqrt(T), (case, M, N, rel_err(c, rc))
+        if bias:
+            assert rel_err(db, rdb) < 1e-5 * math.sqrt(T), (case, M, N, rel_err(db, rdb))
+        else:
+            assert db is None
+    # deterministic: a second launch gives the same bits; beta = 1 accumulates into given outputs (and bias outputs)
+    outs2 = k.gemm_tn_grouped(probs)
+    for (c, db), (c2, db2) in zip(outs, outs2):
+        assert torch.equal(c, c2) and (db is None or torch.equal(db, db2))
+    probs3 = [dict(A=q["A"], B=q["B"], out=c.clone(), beta=1.0, dbias=None if db is None else db.clone(), dbias_beta=1.0)
+              for q, (c, db) in zip(probs, outs)]
+    outs3 = k.gemm_tn_grouped(probs3)
+    for (c3, db3), (rc, rdb), (M, N, bias) in zip(outs3, refs, shapes):
+        assert rel_err(c3, 2 * rc) < 2e-5 * math.sqrt(T)
+        if bias:
+            assert rel_err(db3, 2 * rdb) < 1e-5 * math.sqrt(T)
+    # nothing outside [0:M, 0:N] of a larger output allocation is written (leading dimension > N)
+    M, N, _ = shapes[0]
+    big = torch.full((M + 8, N + 8), 5.0, device=dev)
+    k.gemm_tn_grouped([dict(A=probs[0]["A"], B=probs[0]["B"], out=big[:M, :N], beta=0.0)] + probs[1:])
+    assert rel_err(big[:M, :N], refs[0][0]) < 2e-5 * math.sqrt(T)
+    assert bool((big[M:] == 5.0).all()) and bool((big[:, N:] == 5.0).all())
+
+
+def test_gemm_tn_grouped_agrees_with_the_single_launches(dev):
+    """Same gradients from the grouped stream-K launch and from one split-K launch each: fp32 sums in another order."""
+    k = _k()
+    T = 197 * 64
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+    probs = [dict(A=rnd((T, M), dev, 160 + i), B=rnd((T, N), dev, 170 + i), dbias=True) for i, (M, N) in enumerate(shapes)]
+    outs = k.gemm_tn_grouped(probs)
+    for q, (c, db) in zip(probs, outs):
+        c1, db1 = k.gemm_tn(q["A"], q["B"], want_dbias=True)
+        assert rel_err(c, c1) < 1e-5 and rel_err(db, db1) < 1e-5
+
+
 def test_gemm_tn_identity_asymmetric(dev):
     k = _k()
     T = M = 256
