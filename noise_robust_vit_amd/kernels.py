@@ -281,9 +281,10 @@ def gemm_tn_grouped(problems) -> list:
         outs.append((out, dbias))
     nbytes = int(lib.nrv_gemm_tn_grouped_workspace(ctypes.addressof(arr), len(problems), T)) if len(problems) <= 4 else 0
     if nbytes == 0:                                   # not taken by the grouped kernel: one split-K launch per gradient
-        for q, (out, dbias) in zip(problems, outs):
-            gemm_tn(q["A"], q["B"], out=out, beta=float(q.get("beta", 0.0)) if q.get("out") is not None else 0.0,
-                    dbias=dbias, dbias_beta=float(q.get("dbias_beta", 0.0)) if q.get("dbias") not in (None, True) else 0.0)
+        for i, (q, (out, dbias)) in enumerate(zip(problems, outs)):
+            given_db = q.get("dbias") is not None and q.get("dbias") is not True
+            gemm_tn(q["A"], q["B"], out=out, beta=float(arr[i].beta), dbias=dbias,
+                    dbias_beta=float(q.get("dbias_beta", 0.0)) if given_db else 0.0)
         return outs
     ws = _workspace(nbytes, problems[0]["A"].device)
     flops = sum(2.0 * T * q["A"].shape[1] * q["B"].shape[1] for q in problems)

@@ -63,6 +63,38 @@ class TrainConfig:
     seed: int = 0
 
 
+# aten ops whose ROCm implementation goes through thrust / rocPRIM selection primitives (unique-by-key, partition, compaction).
+# Round 3's MAE step faulted in the first replay of its captured graph inside rocprim::detail::partition_kernel, launched by
+# thrust::unique_by_key_copy from embedding_dense_backward (ROCm debug agent: all resident waves of that kernel with MEM_VIOL;
+# bisected over the repository's history to the graph's stream topology, not to a kernel or index of this repository --
+# profiles/r04_mae_graph_replay_fault_root_cause.txt).  The step of this repository's models contains none of them (mae.py routes
+# its token bookkeeping through the bounds-checked row kernels); a user-supplied compute_loss that does is refused.
+_CAPTURE_UNSAFE_OPS = ("aten.embedding_dense_backward", "aten._embedding_bag_dense_backward", "aten.nonzero", "aten.masked_select",
+                       "aten._unique", "aten.unique_dim", "aten.unique_consecutive", "aten._unique2", "aten.bincount",
+                       "aten.index_put_accumulate")
+
+
+def _record_unsafe_ops(fn) -> set:
+    """Run fn() once (eagerly) and return the names of the ops of _CAPTURE_UNSAFE_OPS it dispatched, forward and backward."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    seen = set()
+
+    class _Rec(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if name.startswith(("aten.index_put", "aten._index_put_impl")):
+                acc = (kwargs or {}).get("accumulate", args[3] if len(args) > 3 else False)
+                if acc:
+                    seen.add("aten.index_put(accumulate=True)")
+            elif name.startswith(_CAPTURE_UNSAFE_OPS):
+                seen.add(name.rsplit(".", 1)[0] if name.count(".") > 1 else name)
+            return func(*args, **(kwargs or {}))
+
+    with torch.autograd.set_multithreading_enabled(False), _Rec():      # the backward runs on this thread: the recorder sees it
+        fn()
+    return seen
+
+
 class Trainer:
     """One process per GPU.  `reducer` (parallel.GradReducer) is None for single-GPU runs."""
 
@@ -172,23 +204,37 @@ class Trainer:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):       # allocator pools, weight-cache job tables, lazy kernel attributes
-                opt.stage_step_scalars(self.cfg.lr)
-                body()
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()   # kept: tools/graph_nodes.py walks the nodes
-        opt.stage_step_scalars(self.cfg.lr)
-        with torch.cuda.graph(graph):
-            self._gloss = body()
-        # roll the state back: nothing above was a training step
-        with torch.no_grad():
-            opt.param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
-        opt.step_count, self.step_idx = saved[3], saved[4]
-        torch.cuda.set_rng_state(rng_state, x.device)
-        from .encoder import WEIGHTS
-        WEIGHTS.refresh_all()
+        graph = None
+        try:
+            with torch.cuda.stream(side):
+                for it in range(max(warmup, 1)):      # allocator pools, weight-cache job tables, lazy kernel attributes
+                    opt.stage_step_scalars(self.cfg.lr)
+                    if it > 0:
+                        body()
+                        continue
+                    # the first warm-up step runs under a dispatch recorder: PyTorch library ops that are not safe to replay from a
+                    # HIP graph on this stack are refused by NAME, before anything is captured (round 3: the sort-based backward of
+                    # nn.Embedding -- thrust::unique_by_key_copy -> rocprim partition_kernel -- faulted in the first replay)
+                    seen = _record_unsafe_ops(body)
+                    if seen:
+                        raise RuntimeError("Trainer.capture: the step runs PyTorch ops that are not replay-safe from a HIP graph on "
+                                           f"ROCm ({', '.join(sorted(seen))}); keep such index bookkeeping out of the step (see mae.py) "
+                                           "or train this model with the eager step")
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()   # kept: tools/graph_nodes.py walks the nodes
+            opt.stage_step_scalars(self.cfg.lr)
+            with torch.cuda.graph(graph):
+                self._gloss = body()
+        finally:
+            # roll the state back, also when the step was refused: nothing above was a training step
+            cur.wait_stream(side)
+            with torch.no_grad():
+                opt.param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
+            opt.step_count, self.step_idx = saved[3], saved[4]
+            torch.cuda.set_rng_state(rng_state, x.device)
+            from .encoder import WEIGHTS
+            WEIGHTS.refresh_all()
         self._graph = graph
 
     def _replay(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

@@ -267,3 +267,23 @@ def test_begin_step_clears_autograd_slots_as_contiguous_ranges():
     mask[o:o + n] = False
     assert torch.all(red.flat[mask] == 0.0)
     assert all(p.grad is red._views[id(p)] for p in net.parameters())
+
+
+def test_capture_recorder_names_the_replay_unsafe_library_ops():
+    """Trainer.capture refuses steps by the NAME of a replay-unsafe PyTorch op (round 3: nn.Embedding's sort-based backward faulted
+    inside rocprim's partition kernel in the first replay), not by `compute_loss is not None`: the recorder sees forward and
+    backward ops of one eager step."""
+    from noise_robust_vit_amd.train import _record_unsafe_ops
+    emb = torch.nn.Embedding(10, 4)
+
+    def bad():
+        w = torch.zeros(5, 4, requires_grad=True)
+        (emb(torch.randint(0, 10, (6,))).sum() + w[torch.tensor([1, 1, 3])].sum()).backward()
+
+    def fine():
+        x = torch.randn(4, 4, requires_grad=True)
+        idx = torch.tensor([[0, 2], [1, 3]])
+        (x * 2).gather(1, idx).sum().backward()           # gather / scatter_add: no selection primitive
+
+    assert _record_unsafe_ops(bad) == {"aten.embedding_dense_backward", "aten.index_put(accumulate=True)"}
+    assert _record_unsafe_ops(fine) == set()

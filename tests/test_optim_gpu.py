@@ -148,6 +148,27 @@ def test_graph_replay_of_the_mae_step_is_bit_equal_to_the_eager_step(dev):
         assert torch.equal(v, p1[k]), k
 
 
+def test_capture_refuses_a_step_with_replay_unsafe_library_ops(dev):
+    """A custom loss that sends gradients through nn.Embedding (thrust::unique_by_key_copy -> rocprim partition_kernel in its
+    backward: the kernel that faulted in round 3's first MAE replay) is refused by name before anything is captured; the MAE
+    step itself contains no such op any more and captures (the tests around this one)."""
+    from noise_robust_vit_amd.train import TrainConfig, Trainer
+    m = _mae_small(dev)
+    extra = torch.nn.Embedding(16, 4).to(dev)
+
+    def loss_with_embedding(mod, xb, yb):
+        return mod(xb) + extra(torch.arange(16, device=xb.device) % 7).sum() * 0.0
+
+    t = Trainer(m, TrainConfig(lr=1e-3), compute_loss=loss_with_embedding)
+    x = torch.randn(8, 3, 64, 64, device=dev).to(torch.bfloat16)
+    y = torch.zeros(8, dtype=torch.int64, device=dev)
+    t.step(x, y)
+    with pytest.raises(RuntimeError, match="embedding_dense_backward"):
+        t.capture(x, y)
+    assert t._graph is None
+    t.step(x, y)                                  # the trainer keeps working eagerly
+
+
 def test_graph_replay_of_the_mae_step_draws_a_fresh_mask_every_replay(dev):
     """Default MAE forward (mae.py:66-71: torch.rand(...).argsort() inside the step): under replay the captured random draw
     takes a new Philox offset every time (torch's graph-safe generator), i.e. the mask changes from step to step, the loss
