@@ -202,6 +202,8 @@ def main():
                          "the 605 MB a ViT-B/16 step exchanges per GPU, never measured)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="CUs the GEMM launches leave free for the collective's kernels when N > 1 (0: none, the default; unmeasured at N > 1)")
+    ap.add_argument("--wgrad", default="default", choices=["default", "grouped", "single"],
+                    help="weight gradients: one grouped stream-K launch per layer, or one split-K launch per gradient (A/B switch)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (Trainer.capture)")
     args = ap.parse_args()
 
@@ -232,6 +234,9 @@ def main():
         args.reserve_cus = max(args.reserve_cus, 0) if world > 1 else 0
         pg_desc = make_process_group(rank, world, device=dev, backend="nccl", max_ctas=args.rccl_max_ctas)   # "nccl" IS RCCL on ROCm
 
+    if args.wgrad != "default":
+        from noise_robust_vit_amd import encoder as _enc
+        _enc.WGRAD_GROUPED = args.wgrad == "grouped"
     kind = ARCHS[args.arch][0]
     batch = args.batch or (128 if args.arch.endswith("l_16") else 256)
     model = build_model(args.arch, robust=args.robust).to(dev).train()

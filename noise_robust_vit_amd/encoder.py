@@ -204,6 +204,13 @@ def wgrad_join() -> None:
 # CU whatever the matrices' tile counts and pays prologue, epilogue and partial-tile traffic once per layer instead of once per
 # gradient (round 4; before: one split-K launch + one slab reduction per gradient).
 _PENDING: list = []
+WGRAD_GROUPED = True             # False: every gradient is its own split-K launch, issued where it is queued (the round-3 schedule)
+
+
+def _queue(meta: BlockMeta, q: dict) -> None:
+    _PENDING.append(q)
+    if not WGRAD_GROUPED:
+        wgrad_flush(meta)
 
 
 def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Tensor]):
@@ -217,18 +224,18 @@ def _dw_db(meta: BlockMeta, dy16: Tensor, x16: Tensor, w: Tensor, b: Optional[Te
             raise NrvError("a fused projection carries no bias")
         block = meta.sink.target_block([pp for pp, _, _ in parts]) if hasattr(meta.sink, "target_block") else None
         if block is not None:
-            _PENDING.append(dict(A=dy16, B=x16, out=block[0], beta=block[1]))
+            _queue(meta, dict(A=dy16, B=x16, out=block[0], beta=block[1]))
             return None, None
         for pp, r0, r1 in parts:
             tw, bw = meta.sink.target(pp)
-            _PENDING.append(dict(A=dy16[:, r0:r1], B=x16, out=tw, beta=bw))
+            _queue(meta, dict(A=dy16[:, r0:r1], B=x16, out=tw, beta=bw))
         return None, None
     tw, bw = _grad_target(meta, w)
     tb, bb = _grad_target(meta, b) if b is not None else (None, 0.0)
     M, N = dy16.shape[1], x16.shape[1]
     out = tw if tw is not None else torch.empty(M, N, dtype=torch.float32, device=dy16.device)
     dbias = None if b is None else (tb if tb is not None else torch.empty(M, dtype=torch.float32, device=dy16.device))
-    _PENDING.append(dict(A=dy16, B=x16, out=out, beta=bw if tw is not None else 0.0, dbias=dbias, dbias_beta=bb if tb is not None else 0.0))
+    _queue(meta, dict(A=dy16, B=x16, out=out, beta=bw if tw is not None else 0.0, dbias=dbias, dbias_beta=bb if tb is not None else 0.0))
     return out, dbias
 
 
@@ -253,10 +260,18 @@ def wgrad_flush(meta: BlockMeta) -> None:
         _WGRAD_KEEP.append(tuple(t for q in probs for t in (q["A"], q["B"])))     # alive until the join
         with torch.cuda.stream(side):
             for g in groups:
-                K.gemm_tn_grouped(g)
+                _issue(g)
         return
     for g in groups:
-        K.gemm_tn_grouped(g)
+        _issue(g)
+
+
+def _issue(group: list) -> None:
+    if WGRAD_GROUPED:
+        K.gemm_tn_grouped(group)
+        return
+    for q in group:
+        K.gemm_tn(q["A"], q["B"], out=q["out"], beta=q["beta"], dbias=q.get("dbias"), dbias_beta=q.get("dbias_beta", 0.0))
 
 
 # ----------------------------------------------------------------------------------------------
