@@ -127,11 +127,12 @@ int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb,
 
 /* All weight gradients of a layer in ONE launch (ABI 11): up to 4 problems C_i[M_i,N_i] = beta_i * C_i + sum_t A_i[t,:]^T B_i[t,:]
  * over the same T token rows (dWqkv, dWo, dW1, dW2 of an encoder block: utils.py:693-706, simple_vit.py:39-41,61-62), optional
- * dbias_i[m] = dbias_beta_i * dbias_i[m] + sum_t A_i[t,m].  Stream-K: the 256 x 256 tiles of all problems x the K-steps of 64
- * token rows are split evenly over one workgroup per CU; partial tiles go through `workspace` and are added in a fixed order
- * (deterministic per CU count).  Same operand rules as nrv_gemm_tn_bf16 (no row remap).  `problems` is a HOST array, read
- * during the call.  nrv_gemm_tn_grouped_workspace returns 0 for a group the kernel does not take (T < 512 token rows, fewer than
- * 8 K-steps of work per CU, more than 2 tiles per CU): issue nrv_gemm_tn_bf16 per problem then. */
+ * dbias_i[m] = dbias_beta_i * dbias_i[m] + sum_t A_i[t,m].  One workgroup per CU, all with the same number of K-steps of 64 token
+ * rows: cohorts of one workgroup per 256 x 256 tile that sweep the same token range in step (operand rows are shared through
+ * L2 / Infinity Cache as in a split-K launch) + a stream-K remainder; partial tiles go through `workspace` and are added in K
+ * order (deterministic per CU count).  Same operand rules as nrv_gemm_tn_bf16 (no row remap).  `problems` is a HOST array, read
+ * during the call.  nrv_gemm_tn_grouped_workspace returns 0 for a group the kernel does not take (fewer than 8 K-steps of work
+ * per CU, more tiles than CUs): issue nrv_gemm_tn_bf16 per problem then. */
 typedef struct nrv_tn_problem {
     const void* A; int64_t lda;          /* bf16 [T, M] */
     const void* B; int64_t ldb;          /* bf16 [T, N] */

@@ -1407,21 +1407,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn8_kernel(const GemmTNP
 }
 
 // ---------------------------------------------------------------------------------------------
-// Grouped stream-K TN GEMM: ALL weight gradients of a layer in one launch.  The 256 x 256 output tiles of up to four problems
-// (same token count T) are numbered consecutively; the work is the flattened space (tile, K-step) of ntiles * nk units, and
-// workgroup w of W = one per CU takes the units [bound(w), bound(w + 1)) -- an equal share, whatever the tile count -- as at most
-// TNG_SEGS segments, one per tile it touches.  Every segment writes its partial tile to a dense slot
-// (slot = TNG_SEGS * w + index of the tile within the workgroup's range) and tng_fixup_kernel adds the slots of a tile in
-// workgroup order into C: deterministic, no atomics, no waiting on other workgroups.
-// Against one split-K launch per gradient (nrv_gemm_tn_bf16): the 256 CUs are full whatever the shapes (a 768 x 768 gradient has
-// 9 tiles, ViT-S's 384 x 384 has 4 with 44 % padding), a workgroup's K loop is T * ntiles / (64 W) steps long instead of
-// T / (64 splits) (ViT-S: 117 instead of 12-37: prologue, epilogue and the 256-KiB partial store are paid once or twice per
-// workgroup and LAYER instead of four times), and the partial traffic is (W + ntiles) tiles per layer instead of 4 W.
-// bound(w) = floor(w * units / W), moved onto a tile boundary when it falls within 3 K-steps of one: every segment has the
-// >= 3 K-steps the phased loop needs (host: nk >= 8 and units / W >= 8).
+// Grouped TN GEMM: ALL weight gradients of a layer in one launch.  The 256 x 256 output tiles of up to four problems (same token
+// count T) are numbered consecutively; one workgroup per CU, every one with the same number of K-steps (Lc = ceil(ntiles nk / W)):
+//   * COHORTS: workgroup v < F ntiles computes tile v % ntiles over the K-steps [c Lc, (c + 1) Lc), c = v / ntiles.  All
+//     workgroups of a cohort start at the same token row and move in step, so at any time the chip reads F (+ 1) token
+//     positions and every operand row is fetched from HBM once per cohort and shared through L2 / Infinity Cache by the tiles
+//     that need it -- as in one split-K launch per gradient.  (A first version gave every workgroup ONE contiguous range of
+//     the flattened (tile, K-step) space: 256 workgroups at 256 token positions, no operand row shared, 5.6 GB of reads per
+//     ViT-B/16 layer instead of 1.2 -- HBM-bound at 6 TB/s, the TN time went from 8.4 to 12.0 ms per step.)
+//   * REMAINDER: the K-steps [F Lc, nk) of all tiles (R per tile) are split evenly, tile after tile, over the Wr = W - F ntiles
+//     workgroups that are left (stream-K: a workgroup takes a contiguous range of that space as up to segs_r segments, range
+//     ends snapped onto tile boundaries within 3 K-steps so that every segment has the >= 3 K-steps the phased loop needs).
+// Every segment writes its partial tile to a dense slot; tng_fixup_kernel adds a tile's slots in K order into C: deterministic,
+// no atomics, no waiting on other workgroups.  Against one split-K launch per gradient: every CU is busy whatever the tile
+// counts (a 768 x 768 gradient has 9 tiles), F + 1..2 partials per tile instead of 7 - 64, one reduction launch per layer.
 // ---------------------------------------------------------------------------------------------
 constexpr int TNG_MAX = 4;                  // problems per launch
-constexpr int TNG_SEGS = 3;                 // tile slots per workgroup (host: units / W >= nk / 2 keeps a range within 3 tiles)
 
 struct TngProblem {
     const bf16_t* A;
@@ -1437,16 +1438,17 @@ struct TngProblem {
 struct GemmTNGParams {
     TngProblem pr[TNG_MAX];
     int nprob, ntiles, nk, T, W;
-    long long units;                        // ntiles * nk
-    float* slots;                           // [TNG_SEGS * W][256 * 256] partial tiles
-    float* bias_slots;                      // [TNG_SEGS * W][256] partial column sums
+    int Lc, F, Wr, R, segs_r;               // cohort length, cohorts, remainder workgroups, remainder K-steps per tile, slots per remainder workgroup
+    float* slots;                           // [F ntiles + Wr segs_r][256 * 256] partial tiles
+    float* bias_slots;                      // [F ntiles + Wr segs_r][256] partial column sums
 };
 
-__host__ __device__ __forceinline__ long long tng_bound(long long w, long long units, int W, int nk) {
-    long long b = w * units / W;
-    const int r = (int)(b % nk);
+// remainder space: units = ntiles * R, workgroup j of Wr takes [bound(j), bound(j + 1))
+__host__ __device__ __forceinline__ long long tng_bound(long long j, long long units, int Wr, int R) {
+    long long b = j * units / Wr;
+    const int r = (int)(b % R);
     if (r < 3) b -= r;
-    else if (nk - r < 3) b += nk - r;
+    else if (R - r < 3) b += R - r;
     return b;
 }
 
@@ -1459,39 +1461,56 @@ __device__ __forceinline__ int tng_problem_of(const GemmTNGParams& p, int tile) 
 }
 
 template <typename C>
+__device__ __forceinline__ void tng_run(const GemmTNGParams& p, int tile, int k0, int k1, int slot, char* smem) {
+    const TngProblem& q = p.pr[tng_problem_of(p, tile)];
+    const int lt = tile - q.tile0;
+    const int tm = lt / q.tiles_n, tn = lt - tm * q.tiles_n;
+    TnSeg sg;
+    sg.A = q.A; sg.B = q.B; sg.lda = q.lda; sg.ldb = q.ldb;
+    sg.M = q.M; sg.N = q.N; sg.m0 = tm * C::TBM; sg.n0 = tn * C::TBN;
+    sg.nk = k1 - k0;
+    sg.t_begin = k0 * BK;
+    const int t_end = k1 * BK < p.T ? k1 * BK : p.T;
+    sg.trem = t_end - sg.t_begin;
+    sg.out = p.slots + (long long)slot * (C::TBM * C::TBN);
+    sg.out_ld = C::TBN;
+    sg.bias_out = (q.dbias != nullptr && tn == 0) ? p.bias_slots + (long long)slot * C::TBM : nullptr;
+    tn8_segment<C>(sg, smem);
+}
+
+template <typename C>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tng_kernel(const GemmTNGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const long long b0 = tng_bound(blockIdx.x, p.units, p.W, p.nk), b1 = tng_bound(blockIdx.x + 1, p.units, p.W, p.nk);
-    const int first_tile = (int)(b0 / p.nk);
-    for (long long u = b0; u < b1;) {                            // workgroup-uniform
-        const int tile = (int)(u / p.nk);
-        const int k0 = (int)(u - (long long)tile * p.nk);
-        const long long tile_end = (long long)(tile + 1) * p.nk;
-        const int k1 = (int)((b1 < tile_end ? b1 : tile_end) - (long long)tile * p.nk);
-        const int pi = tng_problem_of(p, tile);
-        const TngProblem& q = p.pr[pi];
-        const int lt = tile - q.tile0;
-        const int tm = lt / q.tiles_n, tn = lt - tm * q.tiles_n;
-        const int slot = TNG_SEGS * blockIdx.x + (tile - first_tile);
-        TnSeg sg;
-        sg.A = q.A; sg.B = q.B; sg.lda = q.lda; sg.ldb = q.ldb;
-        sg.M = q.M; sg.N = q.N; sg.m0 = tm * C::TBM; sg.n0 = tn * C::TBN;
-        sg.nk = k1 - k0;
-        sg.t_begin = k0 * BK;
-        const int t_end = k1 * BK < p.T ? k1 * BK : p.T;
-        sg.trem = t_end - sg.t_begin;
-        sg.out = p.slots + (long long)slot * (C::TBM * C::TBN);
-        sg.out_ld = C::TBN;
-        sg.bias_out = (q.dbias != nullptr && tn == 0) ? p.bias_slots + (long long)slot * C::TBM : nullptr;
-        tn8_segment<C>(sg, smem);
-        u = (long long)tile * p.nk + k1;
-        __syncthreads();                                         // the epilogue's LDS patches are the next segment's stage buffers
+    // consecutive logical workgroups (one cohort's consecutive tiles: shared operand panels) sit on one XCD
+    const int v = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int ncoh = p.F * p.ntiles;
+    if (v < ncoh) {
+        const int c = v / p.ntiles, tile = v - c * p.ntiles;
+        const int k0 = c * p.Lc;
+        const int k1 = (c == p.F - 1 && p.Wr == 0) ? p.nk : k0 + p.Lc;       // no remainder workgroups: the last cohort runs to the end
+        tng_run<C>(p, tile, k0, k1, v, smem);
+        return;
+    }
+    const int j = v - ncoh;
+    if (j >= p.Wr) return;
+    const long long units = (long long)p.ntiles * p.R;
+    const long long b0 = tng_bound(j, units, p.Wr, p.R), b1 = tng_bound(j + 1, units, p.Wr, p.R);
+    const int first_tile = (int)(b0 / p.R);
+    const int kr = p.F * p.Lc;                                               // first K-step of the remainder
+    for (long long u = b0; u < b1;) {                                        // workgroup-uniform
+        const int tile = (int)(u / p.R);
+        const int r0 = (int)(u - (long long)tile * p.R);
+        const long long tile_end = (long long)(tile + 1) * p.R;
+        const int r1 = (int)((b1 < tile_end ? b1 : tile_end) - (long long)tile * p.R);
+        tng_run<C>(p, tile, kr + r0, kr + r1, ncoh + j * p.segs_r + (tile - first_tile), smem);
+        u = (long long)tile * p.R + r1;
+        __syncthreads();                                                     // the epilogue's LDS patches are the next segment's stage buffers
     }
 }
 
-// C tile = beta * C + the tile's partial slots in workgroup order.  Block = 4 waves on 64 consecutive 16-byte chunks of one tile;
-// wave g sums the contributors g, g + 4, ..., the four sums meet in LDS and are added in the fixed order ((p0 + p1) + (p2 + p3)).
-// The first block of a first-column tile also reduces the bias slots.
+// C tile = beta * C + the tile's partial slots in K order (cohort 0 .. F - 1, then the remainder workgroups in index order).
+// Block = 4 waves on 64 consecutive 16-byte chunks of one tile; wave g sums the contributors g, g + 4, ..., the four sums meet in
+// LDS and are added in the fixed order ((p0 + p1) + (p2 + p3)).  The first block of a first-column tile also reduces the bias slots.
 __global__ __launch_bounds__(256) void tng_fixup_kernel(const GemmTNGParams p) {
     __shared__ f32x4_t part[4][64];
     constexpr int TILE = 256, CHUNKS = TILE * TILE / 4, BLOCKS_PER_TILE = CHUNKS / 64;
@@ -1500,20 +1519,30 @@ __global__ __launch_bounds__(256) void tng_fixup_kernel(const GemmTNGParams p) {
     const TngProblem& q = p.pr[tng_problem_of(p, tile)];
     const int lt = tile - q.tile0;
     const int tm = lt / q.tiles_n, tn = lt - tm * q.tiles_n;
-    // contributors: the workgroups whose unit range meets [tile * nk, (tile + 1) * nk)
-    const long long u0 = (long long)tile * p.nk, u1 = u0 + p.nk;
-    int w0 = (int)(u0 * p.W / p.units);
-    while (w0 > 0 && tng_bound(w0, p.units, p.W, p.nk) > u0) --w0;
-    while (w0 + 1 < p.W && tng_bound(w0 + 1, p.units, p.W, p.nk) <= u0) ++w0;
-    int w1 = w0;
-    while (w1 + 1 < p.W && tng_bound(w1 + 1, p.units, p.W, p.nk) < u1) ++w1;
-    auto slot_of = [&](int w) { return (long long)TNG_SEGS * w + (tile - (int)(tng_bound(w, p.units, p.W, p.nk) / p.nk)); };
+    const int ncoh = p.F * p.ntiles;
+    // remainder contributors: the workgroups whose unit range meets [tile * R, (tile + 1) * R)
+    int j0 = 0, j1 = -1;
+    const long long units = (long long)p.ntiles * p.R;
+    if (p.Wr > 0) {
+        const long long u0 = (long long)tile * p.R, u1 = u0 + p.R;
+        j0 = (int)(u0 * p.Wr / units);
+        while (j0 > 0 && tng_bound(j0, units, p.Wr, p.R) > u0) --j0;
+        while (j0 + 1 < p.Wr && tng_bound(j0 + 1, units, p.Wr, p.R) <= u0) ++j0;
+        j1 = j0;
+        while (j1 + 1 < p.Wr && tng_bound(j1 + 1, units, p.Wr, p.R) < u1) ++j1;
+    }
+    const int ncontrib = p.F + (j1 - j0 + 1);
+    auto slot_of = [&](int i) -> long long {                     // contributor i in K order
+        if (i < p.F) return (long long)i * p.ntiles + tile;
+        const int j = j0 + (i - p.F);
+        return (long long)ncoh + (long long)j * p.segs_r + (tile - (int)(tng_bound(j, units, p.Wr, p.R) / p.R));
+    };
 
     const int c = blk * 64 + lane;                               // chunk of the tile: row c / 64, columns 4 (c % 64) ..
     const int row = c >> 6, col = (c & 63) << 2;
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    for (int w = w0 + g; w <= w1; w += 4)
-        s += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p.slots + slot_of(w) * (TILE * TILE) + row * TILE + col));
+    for (int i = g; i < ncontrib; i += 4)
+        s += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p.slots + slot_of(i) * (TILE * TILE) + row * TILE + col));
     part[g][lane] = s;
     __syncthreads();
     const int m = tm * TILE + row, n = tn * TILE + col;
@@ -1527,7 +1556,7 @@ __global__ __launch_bounds__(256) void tng_fixup_kernel(const GemmTNGParams p) {
         const int mm = tm * TILE + threadIdx.x;
         if (mm < q.M) {
             float b = 0.f;
-            for (int w = w0; w <= w1; ++w) b += p.bias_slots[slot_of(w) * TILE + threadIdx.x];
+            for (int i = 0; i < ncontrib; ++i) b += p.bias_slots[slot_of(i) * TILE + threadIdx.x];
             q.dbias[mm] = q.dbias_beta != 0.f ? q.dbias_beta * q.dbias[mm] + b : b;
         }
     }
@@ -1845,9 +1874,9 @@ extern "C" int nrv_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
 // ---- grouped stream-K form: all weight gradients of a layer in one launch (gemm_tng_kernel) ----------------------------------
 namespace {
 // launch plan of a group, or W == 0 when the grouped kernel does not take it (the caller then issues nrv_gemm_tn_bf16 per problem)
-struct TngPlan { int W, nk, ntiles; long long units; };
+struct TngPlan { int W, nk, ntiles, Lc, F, Wr, R, segs_r; long long nslots; };
 TngPlan tng_plan(const nrv_tn_problem* pr, int n, int64_t T) {
-    TngPlan pl{0, 0, 0, 0};
+    TngPlan pl{};
     if (!pr || n < 1 || n > TNG_MAX || T <= 0 || T > 0x7fffff00ll) return pl;
     long long tiles = 0;
     for (int i = 0; i < n; ++i) {
@@ -1856,10 +1885,24 @@ TngPlan tng_plan(const nrv_tn_problem* pr, int n, int64_t T) {
     }
     const int W = device_cus();
     const long long nk = nrv_cdiv(T, BK);
-    // every segment needs >= 3 K-steps: boundaries snap to tile boundaries within 3 K-steps, so a range must be longer than that
-    // (>= 8) and a tile much longer (nk >= 8); a range may span at most TNG_SEGS tiles (tiles <= 2 W)
-    if (nk < 8 || tiles * nk / W < 8 || tiles > 2ll * W || tiles * nk > 0x3fffffffll) return pl;
-    pl.W = W; pl.nk = (int)nk; pl.ntiles = (int)tiles; pl.units = tiles * nk;
+    if (tiles > W || tiles * nk > 0x3fffffffll) return pl;
+    const long long Lc = nrv_cdiv(tiles * nk, W);                 // K-steps per workgroup
+    if (Lc < 8) return pl;                                        // every segment needs >= 3 K-steps, and a prologue worth paying
+    long long F = nk / Lc;
+    if (F > W / tiles) F = W / tiles;
+    if (F < 1) return pl;
+    long long Wr = W - F * tiles, R = nk - F * Lc;
+    int segs_r = 0;
+    if (Wr > 0 && R >= 16) {
+        const long long per = nrv_cdiv(tiles * R, Wr);            // remainder K-steps per workgroup
+        segs_r = (int)(2 + nrv_cdiv(per, R));
+        if (per < 8 || segs_r > 10) Wr = 0;                       // too fragmented: the last cohort takes the remainder instead
+    } else {
+        Wr = 0;
+    }
+    if (Wr == 0) { R = 0; segs_r = 0; }
+    pl.W = W; pl.nk = (int)nk; pl.ntiles = (int)tiles; pl.Lc = (int)Lc; pl.F = (int)F; pl.Wr = (int)Wr; pl.R = (int)R; pl.segs_r = segs_r;
+    pl.nslots = F * tiles + Wr * segs_r;
     return pl;
 }
 }  // namespace
@@ -1867,7 +1910,7 @@ TngPlan tng_plan(const nrv_tn_problem* pr, int n, int64_t T) {
 extern "C" size_t nrv_gemm_tn_grouped_workspace(const nrv_tn_problem* problems, int nprob, int64_t T) {
     const TngPlan pl = tng_plan(problems, nprob, T);
     if (pl.W == 0) return 0;
-    return (size_t)TNG_SEGS * (size_t)pl.W * (256 * 256 + 256) * 4;
+    return (size_t)pl.nslots * (256 * 256 + 256) * 4;
 }
 
 extern "C" int nrv_gemm_tn_grouped_bf16(const nrv_tn_problem* problems, int nprob, int64_t T,
@@ -1875,7 +1918,7 @@ extern "C" int nrv_gemm_tn_grouped_bf16(const nrv_tn_problem* problems, int npro
     if (!problems || !workspace) return NRV_ERR_NULL;
     const TngPlan pl = tng_plan(problems, nprob, T);
     if (pl.W == 0) return NRV_ERR_SHAPE;
-    if (workspace_bytes < (size_t)TNG_SEGS * (size_t)pl.W * (256 * 256 + 256) * 4) return NRV_ERR_WORKSPACE;
+    if (workspace_bytes < (size_t)pl.nslots * (256 * 256 + 256) * 4) return NRV_ERR_WORKSPACE;
     if (!nrv_aligned16(workspace)) return NRV_ERR_ALIGN;
     GemmTNGParams p;
     int tile0 = 0;
@@ -1895,9 +1938,10 @@ extern "C" int nrv_gemm_tn_grouped_bf16(const nrv_tn_problem* problems, int npro
         q.beta = s.beta; q.dbias_beta = s.dbias_beta;
         tile0 += (int)(nrv_cdiv(s.M, 256) * nrv_cdiv(s.N, 256));
     }
-    p.nprob = nprob; p.ntiles = pl.ntiles; p.nk = pl.nk; p.T = (int)T; p.W = pl.W; p.units = pl.units;
+    p.nprob = nprob; p.ntiles = pl.ntiles; p.nk = pl.nk; p.T = (int)T; p.W = pl.W;
+    p.Lc = pl.Lc; p.F = pl.F; p.Wr = pl.Wr; p.R = pl.R; p.segs_r = pl.segs_r;
     p.slots = static_cast<float*>(workspace);
-    p.bias_slots = p.slots + (size_t)TNG_SEGS * pl.W * 256 * 256;
+    p.bias_slots = p.slots + (size_t)pl.nslots * 256 * 256;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int attr = set_lds(gemm_tng_kernel<TnCfg256>, TnCfg256::LDS);
     if (attr != 0) return attr;

@@ -204,7 +204,7 @@ def wgrad_join() -> None:
 # CU whatever the matrices' tile counts and pays prologue, epilogue and partial-tile traffic once per layer instead of once per
 # gradient (round 4; before: one split-K launch + one slab reduction per gradient).
 _PENDING: list = []
-WGRAD_GROUPED = True             # False: every gradient is its own split-K launch, issued where it is queued (the round-3 schedule)
+WGRAD_GROUPED = False            # True: one grouped launch per layer (kernels.gemm_tn_grouped); False: every gradient is its own split-K launch, issued where it is queued (the round-3 schedule)
 
 
 def _queue(meta: BlockMeta, q: dict) -> None:

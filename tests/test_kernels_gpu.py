@@ -328,6 +328,8 @@ TNG_CASES = {
     "single": (8192, [(512, 512, False)]),
     "mae_dec": (12544, [(1536, 512, False), (512, 512, True), (2048, 512, True), (512, 2048, True)]),
     "too_small": (300, [(256, 256, True), (128, 64, False)]),
+    # 96 tiles x 100 K-steps on 256 CUs: 2 cohorts of 38 K-steps + 64 remainder workgroups over the last 24 K-steps of every tile
+    "cohorts_and_remainder": (6400, [(1536, 1024, True), (1024, 1536, True), (1536, 1024, False), (1000, 1528, True)]),
 }
 
 
