@@ -1886,19 +1886,38 @@ TngPlan tng_plan(const nrv_tn_problem* pr, int n, int64_t T) {
     const int W = device_cus();
     const long long nk = nrv_cdiv(T, BK);
     if (tiles > W || tiles * nk > 0x3fffffffll) return pl;
-    const long long Lc = nrv_cdiv(tiles * nk, W);                 // K-steps per workgroup
+    long long Lc = nrv_cdiv(tiles * nk, W);                       // K-steps per workgroup when all do the same number
     if (Lc < 8) return pl;                                        // every segment needs >= 3 K-steps, and a prologue worth paying
     long long F = nk / Lc;
     if (F > W / tiles) F = W / tiles;
     if (F < 1) return pl;
     long long Wr = W - F * tiles, R = nk - F * Lc;
     int segs_r = 0;
-    if (Wr > 0 && R >= 16) {
-        const long long per = nrv_cdiv(tiles * R, Wr);            // remainder K-steps per workgroup
-        segs_r = (int)(2 + nrv_cdiv(per, R));
-        if (per < 8 || segs_r > 10) Wr = 0;                       // too fragmented: the last cohort takes the remainder instead
-    } else {
-        Wr = 0;
+    if (Wr > 0) {
+        // A remainder workgroup runs several short segments, each with its own prologue, epilogue and partial store (SEG_COST
+        // K-steps' worth, from the tile timeline: ~3 us + 5 - 8 us against 1.6 us per K-step): it gets fewer K-steps than a cohort
+        // workgroup.  Pick the cohort length that levels the two times (with equal K-steps the remainder workgroups finished
+        // last: the grouped launch measured 1 - 2 % behind four split-K launches).
+        constexpr long long SEG_COST = 6;
+        long long best = -1, best_t = 0;
+        for (long long L = Lc; L <= Lc + 40 && F * L < nk; ++L) {
+            const long long r = nk - F * L;
+            if (r < 16) break;
+            const long long per = nrv_cdiv(tiles * r, Wr);
+            if (per < 8) break;
+            const long long segs = 1 + nrv_cdiv(per, r);
+            const long long t_rem = per + segs * SEG_COST, t_coh = L + SEG_COST;
+            const long long t = t_rem > t_coh ? t_rem : t_coh;
+            if (best < 0 || t < best_t) { best = L; best_t = t; }
+        }
+        if (best > 0) {
+            Lc = best; R = nk - F * Lc;
+            const long long per = nrv_cdiv(tiles * R, Wr);
+            segs_r = (int)(2 + nrv_cdiv(per, R));
+            if (segs_r > 12) Wr = 0;
+        } else {
+            Wr = 0;                                               // too fragmented: the last cohort takes the remainder instead
+        }
     }
     if (Wr == 0) { R = 0; segs_r = 0; }
     pl.W = W; pl.nk = (int)nk; pl.ntiles = (int)tiles; pl.Lc = (int)Lc; pl.F = (int)F; pl.Wr = (int)Wr; pl.R = (int)R; pl.segs_r = segs_r;
