@@ -265,20 +265,21 @@ int nrv_scatter_rows_f32(const float* dout, const int64_t* index, float* dsrc,
 /* ------------------------------------------------------------------------------------------
  * Optimizer step on flat fp32 buffers (replaces torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of the reference
  * harness: examples/CIFAR100.py:90-97,191-192, baseline.py:127).
- *   nrv_sumsq_f32 : out[0] = sum_i x[i]^2 (deterministic two-stage reduction; workspace nrv_sumsq_workspace(n) bytes)
+ *   nrv_sumsq_f32 : out[0] = sum_i x[i]^2 (deterministic two-stage reduction; workspace nrv_sumsq_workspace(n) bytes); x fp32 or bf16
  *   nrv_adamw_f32 : for every i:  g = grad[i] * c,  c = min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6))  (c = 1 when gnorm_sq
  *                   is NULL or max_norm <= 0);  p *= 1 - lr * weight_decay;  m = beta1 m + (1 - beta1) g;
  *                   v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
  *                   -- torch.optim.AdamW (amsgrad = False, maximize = False) arithmetic, step >= 1.
  *   Hyper-parameters are doubles (1 - beta and the bias corrections are formed in double, then rounded, as torch does).
- *   p, grad, m, v: fp32 [n], 16-byte aligned; gnorm_sq: DEVICE pointer to one float (no host round trip).
+ *   p, m, v: fp32 [n], 16-byte aligned; grad: fp32 or (ABI 11) bf16 [n] -- the reduced slabs of a bf16 gradient exchange are read in
+ *   place, no conversion pass back into an fp32 buffer; gnorm_sq: DEVICE pointer to one float (no host round trip).
  *   step_scalars (optional, DEVICE pointer to 3 floats): { 1 - lr * weight_decay, lr / (1 - beta1^step),
  *   1 / sqrt(1 - beta2^step) } read by the kernel INSTEAD of the values derived from lr / weight_decay / step -- a captured
  *   HIP graph replays one launch with every step's learning rate and bias corrections (the caller refreshes the 3 floats).
  * ---------------------------------------------------------------------------------------- */
 size_t nrv_sumsq_workspace(int64_t n);
-int nrv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
-int nrv_adamw_f32(float* p, const float* grad, float* m, float* v, int64_t n,
+int nrv_sumsq_f32(const void* x, int x_dtype, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int nrv_adamw_f32(float* p, const void* grad, int grad_dtype, float* m, float* v, int64_t n,
                   double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                   const float* gnorm_sq, float max_norm, const float* step_scalars, void* stream);
 

@@ -65,8 +65,8 @@ SIGNATURES = {
     "nrv_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "nrv_scatter_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "nrv_sumsq_workspace": (c_size_t, [c_int64]),
-    "nrv_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "nrv_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+    "nrv_sumsq_f32": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nrv_adamw_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                               c_double, c_double, c_double, c_double, c_double, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "nrv_sinkhorn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "nrv_sinkhorn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -14,16 +14,31 @@ namespace {
 constexpr int OPT_THREADS = 256;
 constexpr int SUMSQ_BLOCKS = 1024;
 
-__global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const float* __restrict__ x, long long n4, long long n,
+// four gradients at index 4 i: fp32, or bf16 (the reduced bucket slabs of a bf16 gradient exchange: parallel.GradReducer)
+template <bool BF16>
+__device__ __forceinline__ f32x4_t load4(const void* __restrict__ x, long long i) {
+    if (BF16) {
+        const u32x2_t r = *reinterpret_cast<const u32x2_t*>(static_cast<const bf16_t*>(x) + 4 * i);
+        return f32x4_t{bf16lo_to_f32(r[0]), bf16hi_to_f32(r[0]), bf16lo_to_f32(r[1]), bf16hi_to_f32(r[1])};
+    }
+    return *reinterpret_cast<const f32x4_t*>(static_cast<const float*>(x) + 4 * i);
+}
+template <bool BF16>
+__device__ __forceinline__ float load1(const void* __restrict__ x, long long i) {
+    return BF16 ? bf16_to_f32(static_cast<const bf16_t*>(x)[i]) : static_cast<const float*>(x)[i];
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const void* __restrict__ x, long long n4, long long n,
                                                                    float* __restrict__ partial) {
     float s = 0.f;
     const long long stride = (long long)gridDim.x * OPT_THREADS;
     for (long long i = (long long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += stride) {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + 4 * i);
+        const f32x4_t v = load4<BF16>(x, i);
         s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
     }
     if (blockIdx.x == 0)
-        for (long long i = 4 * n4 + threadIdx.x; i < n; i += OPT_THREADS) s = fmaf(x[i], x[i], s);
+        for (long long i = 4 * n4 + threadIdx.x; i < n; i += OPT_THREADS) { const float v = load1<BF16>(x, i); s = fmaf(v, v, s); }
     __shared__ float red[OPT_THREADS / 64];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -68,7 +83,8 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
     p -= a.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <bool GBF16>
+__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ p, const void* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            long long n4, long long n, const float* __restrict__ gnorm_sq,
                                                            const float* __restrict__ step_scalars, AdamWArgs a) {
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ 
     const long long stride = (long long)gridDim.x * OPT_THREADS;
     for (long long i = (long long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += stride) {
         f32x4_t pv = *reinterpret_cast<const f32x4_t*>(p + 4 * i);
-        const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + 4 * i);
+        const f32x4_t gv = load4<GBF16>(g, i);
         f32x4_t mv = *reinterpret_cast<const f32x4_t*>(m + 4 * i);
         f32x4_t vv = *reinterpret_cast<const f32x4_t*>(v + 4 * i);
 #pragma unroll
@@ -100,7 +116,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ 
         *reinterpret_cast<f32x4_t*>(v + 4 * i) = vv;
     }
     if (blockIdx.x == 0)
-        for (long long i = 4 * n4 + threadIdx.x; i < n; i += OPT_THREADS) adamw_one(p[i], g[i], m[i], v[i], a, coef);
+        for (long long i = 4 * n4 + threadIdx.x; i < n; i += OPT_THREADS) adamw_one(p[i], load1<GBF16>(g, i), m[i], v[i], a, coef);
 }
 
 }  // namespace
@@ -109,9 +125,10 @@ extern "C" size_t nrv_sumsq_workspace(int64_t n) {
     return n > 0 ? (size_t)SUMSQ_BLOCKS * 4 : 0;
 }
 
-extern "C" int nrv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nrv_sumsq_f32(const void* x, int x_dtype, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !out || !workspace) return NRV_ERR_NULL;
     if (n <= 0) return NRV_ERR_SHAPE;
+    if (x_dtype != NRV_F32 && x_dtype != NRV_BF16) return NRV_ERR_DTYPE;
     if (!nrv_aligned16(x)) return NRV_ERR_ALIGN;
     if (workspace_bytes < (size_t)SUMSQ_BLOCKS * 4) return NRV_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -120,17 +137,19 @@ extern "C" int nrv_sumsq_f32(const float* x, int64_t n, float* out, void* worksp
     if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
     if (blocks < 1) blocks = 1;
     float* partial = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, x, n4, (long long)n, partial);
+    if (x_dtype == NRV_BF16) hipLaunchKernelGGL(sumsq_partial_kernel<true>, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, x, n4, (long long)n, partial);
+    else hipLaunchKernelGGL(sumsq_partial_kernel<false>, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, x, n4, (long long)n, partial);
     NRV_CHECK_LAUNCH();
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(OPT_THREADS), 0, s, partial, (int)blocks, out);
     NRV_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int nrv_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n,
+extern "C" int nrv_adamw_f32(float* p, const void* g, int g_dtype, float* m, float* v, int64_t n,
                              double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                              const float* gnorm_sq, float max_norm, const float* step_scalars, void* stream) {
     if (!p || !g || !m || !v) return NRV_ERR_NULL;
+    if (g_dtype != NRV_F32 && g_dtype != NRV_BF16) return NRV_ERR_DTYPE;
     if (n <= 0 || step < 1) return NRV_ERR_SHAPE;
     if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return NRV_ERR_SHAPE;
     if (!nrv_aligned16(p) || !nrv_aligned16(g) || !nrv_aligned16(m) || !nrv_aligned16(v)) return NRV_ERR_ALIGN;
@@ -151,7 +170,8 @@ extern "C" int nrv_adamw_f32(float* p, const float* g, float* m, float* v, int64
     long long blocks = (n4 + OPT_THREADS - 1) / OPT_THREADS;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, p, g, m, v, n4, (long long)n, gnorm_sq, step_scalars, a);
+    if (g_dtype == NRV_BF16) hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, p, g, m, v, n4, (long long)n, gnorm_sq, step_scalars, a);
+    else hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, p, g, m, v, n4, (long long)n, gnorm_sq, step_scalars, a);
     NRV_CHECK_LAUNCH();
     return 0;
 }

@@ -544,26 +544,28 @@ def sumsq_workspace(n: int) -> int:
 
 
 def sumsq(x: Tensor, out: Tensor, ws: Tensor) -> None:
-    """out[0] = sum(x^2) for a flat fp32 buffer (deterministic); ws: fp32 scratch of nrv_sumsq_workspace bytes."""
-    _f32(x, "x")
+    """out[0] = sum(x^2) for a flat fp32 or bf16 buffer (deterministic); ws: fp32 scratch of nrv_sumsq_workspace bytes."""
+    _dev(x, "x")
     lib = _lib.load()
-    _run("optimizer", 0.0, x.numel() * 4,
-         lambda: lib.nrv_sumsq_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()),
+    _run("optimizer", 0.0, x.numel() * x.element_size(),
+         lambda: lib.nrv_sumsq_f32(x.data_ptr(), _dt(x, "x"), x.numel(), out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()),
          "nrv_sumsq_f32")
 
 
 def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
                weight_decay: float, step: int, gnorm_sq: Optional[Tensor], max_norm: float,
                step_scalars: Optional[Tensor] = None) -> None:
-    """In-place clip + AdamW on flat fp32 buffers (include/nrv.h: nrv_adamw_f32).  `step_scalars`: device tensor of 3 floats
-    that replaces the step-dependent scalars (graph replay)."""
-    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+    """In-place clip + AdamW on flat buffers (include/nrv.h: nrv_adamw_f32): p, m, v fp32; g fp32 or bf16 (the reduced slabs of a
+    bf16 gradient exchange, read in place).  `step_scalars`: device tensor of 3 floats that replaces the step-dependent scalars
+    (graph replay)."""
+    for t, n in ((p, "p"), (m, "m"), (v, "v")):
         _f32(t, n)
+    _dev(g, "g")
     if not (p.numel() == g.numel() == m.numel() == v.numel()):
         raise NrvError("adamw_flat: buffers differ in length")
     lib = _lib.load()
-    _run("optimizer", 0.0, p.numel() * 28,
-         lambda: lib.nrv_adamw_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+    _run("optimizer", 0.0, p.numel() * (24 + g.element_size()),
+         lambda: lib.nrv_adamw_f32(p.data_ptr(), g.data_ptr(), _dt(g, "g"), m.data_ptr(), v.data_ptr(), p.numel(),
                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                                    _ptr(gnorm_sq), float(max_norm), _ptr(step_scalars), _stream()),
          "nrv_adamw_f32")

@@ -74,15 +74,16 @@ class FusedAdamW:
             self._check_layout()
         if not from_device:
             self.step_count += 1
+        grad = self.reducer.grad_buffer() if hasattr(self.reducer, "grad_buffer") else self.grad     # fp32, or the reduced bf16 image
         if max_norm and max_norm > 0:
-            K.sumsq(self.grad, self.gnorm_sq, self._ws)
+            K.sumsq(grad, self.gnorm_sq, self._ws)
         # parameters without a gradient this step are skipped like torch.optim.AdamW skips `p.grad is None` (no weight decay,
         # no moment update): the flat buffers are walked in the ranges between their slots (normally ONE range).  Single
         # process only -- with a process group every parameter steps (parallel.GradReducer.finish_step).  The bias
         # correction uses the optimizer's global step count; torch keeps a per-parameter count, which differs only for a
         # parameter that skipped steps.
         for lo, hi in self._active_ranges():
-            K.adamw_flat(self.param[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+            K.adamw_flat(self.param[lo:hi], grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                          self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                          max(self.step_count, 1), self.gnorm_sq if max_norm and max_norm > 0 else None, float(max_norm or 0.0),
                          step_scalars=self._dyn if from_device else None)

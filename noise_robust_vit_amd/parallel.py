@@ -166,6 +166,8 @@ class GradReducer:
                 self.buckets[-1] = (s0, cut, ids0[:k])
                 self.buckets.append((cut, e0, ids0[k:]))
         self._stage_slabs: list = []
+        self.flat16: Optional[torch.Tensor] = None        # bf16 image of `flat` (grad_dtype="bf16": allocated at the first exchange)
+        self.reduced_in_bf16 = False
         self._bucket_of = {pid: b for b, (_, _, ids) in enumerate(self.buckets) for pid in ids}
         self._sink_managed: set = set()
         self._ready: set = set()
@@ -247,9 +249,13 @@ class GradReducer:
             self._reserved = True
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         if self.grad_dtype == "bf16":
-            # one bf16 slab per bucket in flight (the staging tensors live until finish_step); cast on the compute stream,
-            # behind the kernels that produced the gradients, in front of the collective
-            slab = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+            # the bucket's range of ONE persistent bf16 image of the flat buffer (same slot layout): cast on the compute stream,
+            # behind the kernels that produced the gradients, in front of the collective.  On the HIP device the reduced image is
+            # what optim.FusedAdamW reads (nrv_sumsq_f32 / nrv_adamw_f32 take bf16 gradients in place, ABI 11): nothing is
+            # converted back into the fp32 buffer.
+            if self.flat16 is None:
+                self.flat16 = torch.zeros(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
+            slab = self.flat16[s:e]
             if self.flat.is_cuda:
                 from . import kernels as K
                 K.cast_bf16(self.flat[s:e], out=slab)
@@ -262,6 +268,7 @@ class GradReducer:
 
     # ---- step protocol -----------------------------------------------------------------------
     def begin_step(self) -> None:
+        self.reduced_in_bf16 = False
         if self._reserved:                      # a backward that raised after the first bucket never reached finish_step: the
             from . import kernels as K          # process-wide CU reservation must not outlive its step
             K.set_reserved_cus(0)
@@ -314,11 +321,21 @@ class GradReducer:
             from . import kernels as K
             K.set_reserved_cus(0)
             self._reserved = False
-        for s, e, slab in self._stage_slabs:          # reduced bf16 means back into the fp32 buffer the optimizer reads
-            self.flat[s:e].copy_(slab)
+        exchanged = bool(self._stage_slabs)
+        self.reduced_in_bf16 = exchanged and self.flat.is_cuda and self._avg_native
+        if exchanged and not self.reduced_in_bf16:
+            # CPU tensors (gloo tests; torch.optim.AdamW reads the fp32 views) or a backend without AVG: the reduced bf16 means go
+            # back into the fp32 buffer.  On the HIP device with RCCL the optimizer reads `flat16` itself (`grad_buffer()`).
+            for s, e, slab in self._stage_slabs:
+                self.flat[s:e].copy_(slab)
         self._stage_slabs = []
         if (self.world > 1 or self.force) and not self._avg_native and dist.is_initialized():
             self.flat.mul_(1.0 / self.world)
+
+    def grad_buffer(self) -> torch.Tensor:
+        """The flat buffer that holds the step's final gradients (valid between finish_step and begin_step): the fp32 buffer, or
+        -- after a bf16 exchange on the HIP device -- its reduced bf16 image, which every bucket has overwritten."""
+        return self.flat16 if self.reduced_in_bf16 else self.flat
 
     def bucket_bytes(self) -> List[int]:
         return [(e - s) * 4 for s, e, _ in self.buckets]

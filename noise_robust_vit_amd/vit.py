@@ -38,7 +38,8 @@ class MultiheadAttention(nn.Module):
     packed `in_proj_weight [3E, E]`, `in_proj_bias [3E]`, `out_proj` Linear(E, E) with bias.
 
     `forward(x, x, x, need_weights=False)` runs fused self-attention and returns `(out, None)` like the
-    reference's call site expects (vit.py:124).  Only the self-attention form used by `EncoderBlock` exists.
+    reference's call site expects (vit.py:124); `need_weights=True` also returns the attention weights (recomputed, no
+    gradient).  Only the self-attention form used by `EncoderBlock` exists (no masks, dropout p = 0).
     """
 
     def __init__(self, embed_dim, num_heads, dropout=0.0, bias=True, add_bias_kv=False, add_zero_attn=False,
@@ -68,16 +69,26 @@ class MultiheadAttention(nn.Module):
         all in libnrv_hip.so.  `batch_first=False` takes / returns [S, B, E] like torch's module."""
         if (key is not None and key is not query) or (value is not None and value is not query):
             raise NotImplementedError("self-attention only (query is key is value), as EncoderBlock calls it")
-        if need_weights:
-            raise NotImplementedError("the fused kernel never materialises attention weights (use recorder.Recorder)")
         if key_padding_mask is not None or attn_mask is not None:
             raise NotImplementedError("attention masks are outside the encoder hot path")
         if self.training:
             _no_dropout(self.dropout, "attention dropout")
         x = query if self.batch_first else query.transpose(0, 1)
         meta = BlockMeta(heads=self.num_heads, dim_head=self.head_dim, eps=0.0, robust=bool(self.robust))
-        out = AttnHalfFn.apply(x, meta, None, None, *self.attn_params())
-        return (out if self.batch_first else out.transpose(0, 1)), None
+        if not need_weights:
+            out = AttnHalfFn.apply(x, meta, None, None, *self.attn_params())
+            return (out if self.batch_first else out.transpose(0, 1)), None
+        # need_weights=True (utils.py:741-751, 594-597): the fused kernels never materialise the weights, so they are recomputed from
+        # q, k and the saved statistics (nrv_attn_probs; the Sinkhorn-scaled matrix for robust=True) -- [B, N, N] averaged over the
+        # heads as torch's module returns them by default, [B, H, N, N] with average_attn_weights=False; introspection: no gradient
+        from .encoder import record_attention
+        maps: list = []
+        with record_attention(maps):
+            out = AttnHalfFn.apply(x, meta, None, None, *self.attn_params())
+        w = maps[-1]
+        if kw.get("average_attn_weights", True):
+            w = w.mean(dim=1)
+        return (out if self.batch_first else out.transpose(0, 1)), w
 
 
 class MLPBlock(nn.Sequential):

@@ -88,7 +88,8 @@ import torch.distributed as dist
 from noise_robust_vit_amd import VisionTransformer
 from noise_robust_vit_amd.parallel import GradReducer
 from noise_robust_vit_amd.train import Trainer, TrainConfig
-use_rccl = sys.argv[3] == "rccl"
+use_rccl = sys.argv[3] in ("rccl", "rccl_bf16")
+grad_dtype = "bf16" if sys.argv[3] == "rccl_bf16" else "fp32"
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 if use_rccl:
@@ -100,7 +101,7 @@ torch.manual_seed(0)
 m = VisionTransformer(image_size=32, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10)
 torch.nn.init.normal_(m.heads.head.weight, std=0.02)
 m = m.to(dev).train()
-red = GradReducer(m, 1, bucket_mib=0.5, force_collectives=True) if use_rccl else None
+red = GradReducer(m, 1, bucket_mib=0.5, force_collectives=True, grad_dtype=grad_dtype) if use_rccl else None
 ncalls = [0]
 if use_rccl:
     assert dist.get_backend() == "nccl" and red._avg_native
@@ -118,6 +119,11 @@ tr.forward_backward(x, y)
 acc = tr.eval_step(x, y).item()
 torch.cuda.synchronize()
 out = {"loss": losses, "acc": acc, "nbuckets": len(red.buckets) if red else 0, "ncalls": ncalls[0]}
+if grad_dtype == "bf16":
+    # after finish_step the reduced gradients live in the bf16 image (one rank: AVG is the identity, so it is the rounded fp32 buffer)
+    out["reduced_in_bf16"] = bool(red.reduced_in_bf16)
+    out["image_is_rounded_flat"] = bool(torch.equal(red.grad_buffer(), red.flat.to(torch.bfloat16)))
+    out["grad_buffer_dtype"] = str(red.grad_buffer().dtype)
 for k, p in m.named_parameters():
     out["g." + k] = p.grad.detach().float().cpu().reshape(-1).tolist()[:256]
     out["w." + k] = p.detach().float().cpu().reshape(-1).tolist()[:256]
@@ -149,6 +155,36 @@ def test_rccl_process_group_on_one_gpu_matches_plain_run(dev, tmp_path):
     for k in a:
         if k.startswith(("g.", "w.")):
             assert a[k] == b[k], k
+
+
+def test_bf16_gradient_exchange_is_read_in_place_by_the_optimizer(dev, tmp_path):
+    """grad_dtype="bf16" on the HIP device: every bucket is cast into ONE persistent bf16 image of the flat buffer,
+    all-reduced there, and clip + AdamW read that image (nrv_sumsq_f32 / nrv_adamw_f32 take bf16 gradients, ABI 11) -- no pass back
+    into the fp32 buffer.  One-rank RCCL group: the trajectory is the plain run's with gradients rounded to bf16 once per step."""
+    import json
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    outs = {}
+    for mode in ("plain", "rccl_bf16"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = tmp_path / f"{mode}.json"
+        r = subprocess.run([sys.executable, str(script), ROOT, str(out), mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[mode] = json.load(open(out))
+    a, b = outs["plain"], outs["rccl_bf16"]
+    assert b["reduced_in_bf16"] and b["image_is_rounded_flat"] and b["grad_buffer_dtype"] == "torch.bfloat16"
+    assert b["ncalls"] == 4 * b["nbuckets"]
+    assert a["loss"][0] == b["loss"][0]                            # the first loss precedes any update
+    for la, lb in zip(a["loss"], b["loss"]):
+        assert abs(la - lb) < 5e-3 * abs(la), (a["loss"], b["loss"])
+    worst = 0.0
+    for k in a:
+        if k.startswith("w."):
+            wa, wb = torch.tensor(a[k]), torch.tensor(b[k])
+            worst = max(worst, ((wa - wb).norm() / wa.norm().clamp_min(1e-12)).item())
+    assert worst < 2e-3, worst                                     # 3 AdamW steps of lr 1e-3 on gradients rounded to 8 bits
 
 
 def test_bench_under_the_distributed_launcher_one_rank(dev, tmp_path):

@@ -569,8 +569,18 @@ def test_multihead_attention_forward_matches_torch_module(dev, batch_first):
         g = g.detach().float().cpu().reshape(-1); r = r.reshape(-1)
         rel = ((g - r).norm() / r.norm()).item()
         assert rel < 2e-2, (name, rel)
+    # need_weights=True: the attention weights torch's module returns (averaged over the heads by default), recomputed from q, k
+    # and the saved log-sum-exp; the output is the same fused result
+    with torch.no_grad():
+        out2, w_avg = mine(xd, xd, xd, need_weights=True)
+        _, w_all = mine(xd, xd, xd, need_weights=True, average_attn_weights=False)
+        _, rw_avg = ref(x, x, x, need_weights=True)
+        _, rw_all = ref(x, x, x, need_weights=True, average_attn_weights=False)
+    assert torch.equal(out2, out.detach())
+    assert w_avg.shape == rw_avg.shape == (B, S, S) and w_all.shape == rw_all.shape == (B, H, S, S)
+    assert (w_avg.cpu() - rw_avg).abs().max().item() < 5e-3 and (w_all.cpu() - rw_all).abs().max().item() < 5e-3
     with pytest.raises(NotImplementedError):
-        mine(xd, xd, xd, need_weights=True)
+        mine(xd, xd, xd, attn_mask=torch.zeros(S, S, device=dev))
 
 
 def test_state_dict_roundtrip_and_legacy_mlp_keys(dev):

@@ -111,6 +111,28 @@ def test_graph_replay_of_the_whole_step_is_bit_equal_to_the_eager_step(dev):
         assert torch.equal(v, p1[k]), k
 
 
+def test_optimizer_kernels_read_bf16_gradients_in_place(dev):
+    """nrv_sumsq_f32 / nrv_adamw_f32 with a bf16 gradient buffer (ABI 11) = the same kernels on that buffer converted to fp32, bit for bit."""
+    from noise_robust_vit_amd import kernels as K
+    n = 1000003
+    g0 = torch.Generator(device="cpu").manual_seed(5)
+    p = torch.randn(n, generator=g0).to(dev)
+    g16 = (torch.randn(n, generator=g0) * 0.3).to(dev).to(torch.bfloat16)
+    g32 = g16.float()
+    res = []
+    for g in (g16, g32):
+        pp, m, v = p.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        ss = torch.zeros(1, device=dev)
+        ws = torch.empty(max(K.sumsq_workspace(n) // 4, 4), device=dev)
+        K.sumsq(g, ss, ws)
+        for step in (1, 2):
+            K.adamw_flat(pp, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, step, ss, 1.0)
+        res.append((ss.clone(), pp, m, v))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert abs(res[0][0].item() - (g32.double() ** 2).sum().item()) < 1e-5 * res[0][0].item()
+
+
 def _mae_small(dev):
     from noise_robust_vit_amd.encoder import WEIGHTS
     from noise_robust_vit_amd.lucid_vit import ViT
