@@ -18,6 +18,7 @@ from typing import Dict
 import torch
 
 from . import kernels as K
+from .parallel import _slot_len
 from ._lib import NrvError
 
 
@@ -100,7 +101,7 @@ class FusedAdamW:
         for o, n in skip:
             if o > cur:
                 out.append((cur, o))
-            cur = o + (n + 3) // 4 * 4
+            cur = o + _slot_len(n)
         if cur < self.grad.numel():
             out.append((cur, self.grad.numel()))
         return out

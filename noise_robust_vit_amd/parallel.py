@@ -34,6 +34,13 @@ import torch
 import torch.distributed as dist
 
 
+SLOT_ALIGN = 8        # elements: 32 bytes of the fp32 buffer, 16 bytes of its bf16 image (`flat16`) -- kernel operands need 16
+
+
+def _slot_len(n: int) -> int:
+    return (n + SLOT_ALIGN - 1) // SLOT_ALIGN * SLOT_ALIGN
+
+
 def make_process_group(rank: int, world: int, device=None, backend: str = "nccl", max_ctas: int = 0, min_ctas: int = 0,
                        high_priority_stream: bool = False, **kw):
     """`dist.init_process_group` with the RCCL communicator's CU budget made explicit ("nccl" IS RCCL on ROCm).
@@ -126,11 +133,11 @@ class GradReducer:
             order = regrouped
         dev = params[0].device
         sizes = [p.numel() for p in order]
-        # 16-byte aligned slots so every view can be a kernel output
+        # slots of SLOT_ALIGN elements: every view (and every bucket range of the bf16 image) can be a kernel operand
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
-            total += (n + 3) // 4 * 4
+            total += _slot_len(n)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self._slot: Dict[int, Tuple[int, int]] = {}
         self._views: Dict[int, torch.Tensor] = {}
@@ -145,7 +152,7 @@ class GradReducer:
         cur_start, cur_ids = 0, []
         for p, o, n in zip(order, offs, sizes):
             cur_ids.append(id(p))
-            end = o + (n + 3) // 4 * 4
+            end = o + _slot_len(n)
             if end - cur_start >= cap:
                 self.buckets.append((cur_start, end, cur_ids))
                 cur_start, cur_ids = end, []
@@ -209,7 +216,7 @@ class GradReducer:
         end = start
         for q in params:
             o, n = self._slot[id(q)]
-            if o != end or n % 4 or q.dim() != 2 or q.shape[1] != params[0].shape[1]:
+            if o != end or n % SLOT_ALIGN or q.dim() != 2 or q.shape[1] != params[0].shape[1]:
                 return None
             end = o + n
         for q in params:
@@ -290,7 +297,7 @@ class GradReducer:
         parameters grew: it is only known after the first backward)."""
         key = len(self._sink_managed)
         if getattr(self, "_zr_key", None) != key:
-            spans = sorted((o, o + (n + 3) // 4 * 4) for pid, (o, n) in self._slot.items() if pid not in self._sink_managed)
+            spans = sorted((o, o + _slot_len(n)) for pid, (o, n) in self._slot.items() if pid not in self._sink_managed)
             runs: List[List[int]] = []
             for a, b in spans:
                 if runs and runs[-1][1] == a:

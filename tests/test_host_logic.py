@@ -230,8 +230,8 @@ def test_grad_reducer_places_grouped_parameters_back_to_back():
     # slots tile the flat buffer without overlap
     spans = sorted(red.slot(p) for p in red.parameters())
     for (o0, n0), (o1, _) in zip(spans, spans[1:]):
-        assert o0 + (n0 + 3) // 4 * 4 == o1
-    assert spans[-1][0] + (spans[-1][1] + 3) // 4 * 4 == red.flat.numel()
+        assert o0 + (n0 + 7) // 8 * 8 == o1                     # slots of parallel.SLOT_ALIGN = 8 elements
+    assert spans[-1][0] + (spans[-1][1] + 7) // 8 * 8 == red.flat.numel()
 
 
 def test_begin_step_releases_a_cu_reservation_left_by_an_aborted_backward(monkeypatch):
