@@ -179,12 +179,11 @@ def test_bf16_gradient_exchange_is_read_in_place_by_the_optimizer(dev, tmp_path)
     assert a["loss"][0] == b["loss"][0]                            # the first loss precedes any update
     for la, lb in zip(a["loss"], b["loss"]):
         assert abs(la - lb) < 5e-3 * abs(la), (a["loss"], b["loss"])
-    worst = 0.0
-    for k in a:
-        if k.startswith("w."):
-            wa, wb = torch.tensor(a[k]), torch.tensor(b[k])
-            worst = max(worst, ((wa - wb).norm() / wa.norm().clamp_min(1e-12)).item())
-    assert worst < 2e-3, worst                                     # 3 AdamW steps of lr 1e-3 on gradients rounded to 8 bits
+    # AdamW moves every element by about lr per step whatever the gradient's size, so an element whose gradient is rounding noise
+    # can end up 2 lr x steps away: the bound is absolute (3 steps of lr 1e-3), and almost all elements agree far better
+    diffs = torch.cat([(torch.tensor(a[k]) - torch.tensor(b[k])).abs() for k in a if k.startswith("w.")])
+    assert diffs.max().item() < 1e-2, diffs.max().item()
+    assert diffs.median().item() < 2e-5 and diffs.mean().item() < 3e-4, (diffs.median().item(), diffs.mean().item())
 
 
 def test_bench_under_the_distributed_launcher_one_rank(dev, tmp_path):
