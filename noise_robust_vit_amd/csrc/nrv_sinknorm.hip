@@ -15,8 +15,41 @@
 
 namespace {
 
-constexpr int SN_THREADS = 256;
+constexpr int SN_THREADS = 1024;
 constexpr int SN_WAVES = SN_THREADS / 64;
+constexpr int SN_CHUNK = 512;               // columns of one column-step pass: 8 per lane
+constexpr int SN_PART_FLOATS = SN_WAVES * SN_CHUNK;
+
+// column sums  t[j] = sum_i w_i(j),  w given per (row, column) by `term(i, j)`: wave w adds the rows i = w, w + 16, ... for 8 columns per
+// lane (independent accumulators: 8 loads in flight per lane instead of one dependent chain down a column -- the first form, one
+// thread per column walking all R rows, was latency-bound: 12 ms per call at 384 heads of 577 x 577), the 16 partial sums meet in LDS
+// and are added in wave order (deterministic).  `emit(j, sum)` runs once per column.
+template <typename Term, typename Emit>
+__device__ __forceinline__ void column_sums(float* part /* [SN_WAVES][SN_CHUNK] */, int R, int C, int tid, Term term, Emit emit) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c0 = 0; c0 < C; c0 += SN_CHUNK) {
+        float acc[SN_CHUNK / 64];
+#pragma unroll
+        for (int k = 0; k < SN_CHUNK / 64; ++k) acc[k] = 0.f;
+        for (int i = wave; i < R; i += SN_WAVES) {
+#pragma unroll
+            for (int k = 0; k < SN_CHUNK / 64; ++k) {
+                const int j = c0 + lane + 64 * k;
+                if (j < C) acc[k] += term(i, j);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SN_CHUNK / 64; ++k) part[wave * SN_CHUNK + lane + 64 * k] = acc[k];
+        __syncthreads();
+        for (int jj = tid; jj < SN_CHUNK && c0 + jj < C; jj += SN_THREADS) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < SN_WAVES; ++w) sum += part[w * SN_CHUNK + jj];
+            emit(c0 + jj, sum);
+        }
+        __syncthreads();
+    }
+}
 
 // forward: scores [G,R,C] -> out [G,R,C]; lse [G,R]; avec [G, iters + 1, R] (cumulative row scalings a_1 .. a_{iters+1});
 // bvec [G, iters, C] (cumulative column scalings b_1 .. b_iters)
@@ -26,6 +59,7 @@ __global__ __launch_bounds__(SN_THREADS) void sinknorm_fwd_kernel(const float* _
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* a = sm;            // [R]
     float* b = sm + R;        // [C]
+    float* part = sm + R + C; // [SN_WAVES][SN_CHUNK]
     const long long g = blockIdx.x;
     const float* Sg = S + g * (long long)R * C;
     float* Pg = out + g * (long long)R * C;
@@ -66,14 +100,12 @@ __global__ __launch_bounds__(SN_THREADS) void sinknorm_fwd_kernel(const float* _
         __syncthreads();
         if (it == iters) break;
         // column step: b_j = 1 / sum_i a_i P0_ij
-        for (int j = tid; j < C; j += SN_THREADS) {
-            float s = 0.f;
-            for (int i = 0; i < R; ++i) s = fmaf(a[i], Pg[(long long)i * C + j], s);
-            const float v = 1.0f / s;
-            b[j] = v;
-            bg[(long long)it * C + j] = v;
-        }
-        __syncthreads();
+        column_sums(part, R, C, tid, [&](int i, int j) { return a[i] * Pg[(long long)i * C + j]; },
+                    [&](int j, float sum) {
+                        const float v = 1.0f / sum;
+                        b[j] = v;
+                        bg[(long long)it * C + j] = v;
+                    });
     }
     // P = diag(a) P0 diag(b), in place
     for (int i = wave; i < R; i += SN_WAVES) {
@@ -92,6 +124,7 @@ __global__ __launch_bounds__(SN_THREADS) void sinknorm_bwd_kernel(const float* _
     float* a = sm;            // [R]  a_k of the step being undone
     float* b = sm + R;        // [C]
     float* t = sm + R + C;    // [max(R, C)]  per-row / per-column correction
+    float* part = t + (R > C ? R : C);     // [SN_WAVES][SN_CHUNK]
     const long long g = blockIdx.x;
     const float* Sg = S + g * (long long)R * C;
     const float* dPg = dP + g * (long long)R * C;
@@ -126,13 +159,8 @@ __global__ __launch_bounds__(SN_THREADS) void sinknorm_bwd_kernel(const float* _
         for (int i = tid; i < R; i += SN_THREADS) a[i] = ag[(long long)(it - 1) * R + i];
         for (int j = tid; j < C; j += SN_THREADS) b[j] = bg[(long long)(it - 1) * C + j];
         __syncthreads();
-        for (int j = tid; j < C; j += SN_THREADS) {
-            const float bj = b[j];
-            float s = 0.f;
-            for (int i = 0; i < R; ++i) s = fmaf(Gg[(long long)i * C + j], a[i] * p0(i, j) * bj, s);
-            t[j] = s;
-        }
-        __syncthreads();
+        column_sums(part, R, C, tid, [&](int i, int j) { return Gg[(long long)i * C + j] * (a[i] * p0(i, j) * b[j]); },
+                    [&](int j, float sum) { t[j] = sum; });
         for (int i = wave; i < R; i += SN_WAVES) {
             float* grow = Gg + (long long)i * C;
             for (int j = lane; j < C; j += 64) {
@@ -165,7 +193,10 @@ extern "C" int nrv_sinkhorn_fwd(const float* scores, float* out, float* lse, flo
     if (!scores || !out || !lse || !avec || (iters > 0 && !bvec)) return NRV_ERR_NULL;
     if (int e = sn_check(G, R, C, iters)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sinknorm_fwd_kernel, dim3((unsigned)G), dim3(SN_THREADS), (size_t)(R + C) * 4, s,
+    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinknorm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (4096 * 2 + SN_PART_FLOATS) * 4);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL(sinknorm_fwd_kernel, dim3((unsigned)G), dim3(SN_THREADS), (size_t)(R + C + SN_PART_FLOATS) * 4, s,
                        scores, out, lse, avec, bvec, R, C, iters);
     NRV_CHECK_LAUNCH();
     return 0;
@@ -176,7 +207,10 @@ extern "C" int nrv_sinkhorn_bwd(const float* scores, const float* dout, const fl
     if (!scores || !dout || !lse || !avec || (iters > 0 && !bvec) || !dscores) return NRV_ERR_NULL;
     if (int e = sn_check(G, R, C, iters)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sinknorm_bwd_kernel, dim3((unsigned)G), dim3(SN_THREADS), (size_t)(R + C + (R > C ? R : C)) * 4, s,
+    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinknorm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (4096 * 3 + SN_PART_FLOATS) * 4);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL(sinknorm_bwd_kernel, dim3((unsigned)G), dim3(SN_THREADS), (size_t)(R + C + (R > C ? R : C) + SN_PART_FLOATS) * 4, s,
                        scores, dout, lse, avec, bvec, dscores, R, C, iters);
     NRV_CHECK_LAUNCH();
     return 0;
