@@ -9,8 +9,8 @@
 // [B*N, 3*H*dh] projection, transposes and fp32 [B,H,N,N] matrices need no copies.  Operands are rounded to bf16 when they are
 // staged into LDS (P7 and dS enter their products in bf16 exactly as in the fused kernels, DESIGN.md "Numerics").
 //
-// One workgroup (4 waves) per 64 x 64 tile of C, K-steps of 32: both operands are staged element-wise into [64][32] bf16 row
-// images (k contiguous, rows padded to 80 bytes), wave w owns rows 16 w .. 16 w + 15 of the tile and all 64 columns
+// One workgroup (4 waves) per 64 x 64 tile of C, K-steps of 32: both operands are staged into [64][32] bf16 row images (k contiguous,
+// rows padded to 80 bytes; 16-byte loads along the operand's unit stride where its addresses allow, else element by element), wave w owns rows 16 w .. 16 w + 15 of the tile and all 64 columns
 // (4 MFMA 16x16x32 accumulators).  Not tuned: the HBM-bound Sinkhorn sweeps over the materialised matrices dominate this path.
 #include "nrv_common.hpp"
 
@@ -34,11 +34,78 @@ struct BgParams {
     int c_f32;
     int G2, M, N, K;
     int tiles_m, tiles_n;
+    int a_vec, b_vec;                    // 16-byte vector loads along the operand's unit stride (bg_vec_ok)
     float alpha;
 };
 
 __device__ __forceinline__ float bg_load(const BgOperand& o, long long off) {
     return o.f32 ? static_cast<const float*>(o.p)[off] : bf16_to_f32(static_cast<const bf16_t*>(o.p)[off]);
+}
+
+// 16-byte vectors that are only dword-aligned in memory (rows of an fp32 [N, N] matrix with odd N; head slices at any even element)
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Stage one [64 rows][32 k] operand tile into its bf16 row image (element (r, k) at img + r * BG_RS + 2 k).  `rs_row` / `rs_k` are the
+// element strides along the tile's rows / along k.  `vec` (host): the operand's unit-stride direction can be read 16 bytes at a
+// time (8 bf16 / 4 fp32 per load: one or two loads per thread and K-step instead of eight); otherwise element by element.
+__device__ __forceinline__ void bg_stage(const BgOperand& o, char* img, long long base, long long rs_row, long long rs_k,
+                                         int row0, int rows, int k0, int K, int vec, int tid) {
+    if (vec == 0) {
+        const bool kfast = rs_k == 1 || rs_row != 1;
+#pragma unroll
+        for (int i = 0; i < BG_T * BG_K / BG_THREADS; ++i) {
+            const int idx = i * BG_THREADS + tid;
+            const int r = kfast ? idx / BG_K : idx % BG_T, k = kfast ? idx % BG_K : idx / BG_T;
+            float v = 0.f;
+            if (row0 + r < rows && k0 + k < K) v = bg_load(o, base + (long long)(row0 + r) * rs_row + (long long)(k0 + k) * rs_k);
+            *reinterpret_cast<bf16_t*>(img + r * BG_RS + k * 2) = f32_to_bf16(v);
+        }
+        return;
+    }
+    const int VEC = o.f32 ? 4 : 8;
+    const bool kfast = rs_k == 1;                                   // else rs_row == 1 (host)
+    const int items = BG_T * BG_K / VEC;                            // 256 (bf16) or 512 (fp32)
+    for (int it = tid; it < items; it += BG_THREADS) {
+        int r, k;
+        if (kfast) { const int per = BG_K / VEC; r = it / per; k = (it - r * per) * VEC; }
+        else { const int per = BG_T / VEC; k = it / per; r = (it - k * per) * VEC; }
+        const long long off = base + (long long)(row0 + r) * rs_row + (long long)(k0 + k) * rs_k;
+        float v[8];
+        const bool full = kfast ? (row0 + r < rows && k0 + k + VEC <= K) : (row0 + r + VEC <= rows && k0 + k < K);
+        if (full) {
+            if (o.f32) {
+                const f32x4_u t = *reinterpret_cast<const f32x4_u*>(static_cast<const float*>(o.p) + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = t[e];
+            } else {
+                const u32x4_u t = *reinterpret_cast<const u32x4_u*>(static_cast<const bf16_t*>(o.p) + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] = bf16lo_to_f32(t[e]); v[2 * e + 1] = bf16hi_to_f32(t[e]); }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = 0.f;
+                if (e < VEC) {
+                    const int rr = kfast ? r : r + e, kk = kfast ? k + e : k;
+                    if (row0 + rr < rows && k0 + kk < K) v[e] = bg_load(o, off + (long long)e);       // unit stride along the vector
+                }
+            }
+        }
+        if (kfast) {                                                // VEC consecutive k of one row: one 8- or 16-byte LDS store
+            if (o.f32) {
+                *reinterpret_cast<u32x2_t*>(img + r * BG_RS + k * 2) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            } else {
+                *reinterpret_cast<u32x4_t*>(img + r * BG_RS + k * 2) =
+                    u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            }
+        } else {                                                    // VEC consecutive rows of one k
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < VEC) *reinterpret_cast<bf16_t*>(img + (r + e) * BG_RS + k * 2) = f32_to_bf16(v[e]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BgParams p) {
@@ -53,31 +120,14 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BgParams p) {
     const int m0 = tm * BG_T, n0 = tn * BG_T;
     const long long abase = (long long)g1 * p.A.b1 + (long long)g2 * p.A.b2;
     const long long bbase = (long long)g1 * p.B.b1 + (long long)g2 * p.B.b2;
-    // thread -> (row, k) of a [64][32] image: the fast index follows the operand's unit stride so that a wave's loads coalesce
-    const bool a_kfast = p.A.cs == 1 || p.A.rs != 1;          // A[m][k]: k is its column
-    const bool b_kfast = p.B.rs == 1 && p.B.cs != 1;          // B[k][n]: k is its row
 
     f32x4_t acc[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     for (int k0 = 0; k0 < p.K; k0 += BG_K) {
-#pragma unroll
-        for (int i = 0; i < BG_T * BG_K / BG_THREADS; ++i) {
-            const int idx = i * BG_THREADS + tid;
-            {
-                const int r = a_kfast ? idx / BG_K : idx % BG_T, k = a_kfast ? idx % BG_K : idx / BG_T;
-                float v = 0.f;
-                if (m0 + r < p.M && k0 + k < p.K) v = bg_load(p.A, abase + (long long)(m0 + r) * p.A.rs + (long long)(k0 + k) * p.A.cs);
-                *reinterpret_cast<bf16_t*>(aimg + r * BG_RS + k * 2) = f32_to_bf16(v);
-            }
-            {
-                const int r = b_kfast ? idx / BG_K : idx % BG_T, k = b_kfast ? idx % BG_K : idx / BG_T;
-                float v = 0.f;
-                if (n0 + r < p.N && k0 + k < p.K) v = bg_load(p.B, bbase + (long long)(k0 + k) * p.B.rs + (long long)(n0 + r) * p.B.cs);
-                *reinterpret_cast<bf16_t*>(bimg + r * BG_RS + k * 2) = f32_to_bf16(v);
-            }
-        }
+        bg_stage(p.A, aimg, abase, p.A.rs, p.A.cs, m0, p.M, k0, p.K, p.a_vec, tid);       // A[m][k]: rows m, k along its columns
+        bg_stage(p.B, bimg, bbase, p.B.cs, p.B.rs, n0, p.N, k0, p.K, p.b_vec, tid);       // B[k][n]: rows n of the image, k along B's rows
         __syncthreads();
         // fragments: lane -> row (lane & 15) of its 16-row block, k = 8 (lane >> 4) .. + 7
         const bf16x8_t af = lds_read_b128(aimg + (wave * 16 + (lane & 15)) * BG_RS + (lane >> 4) * 16);
@@ -106,6 +156,16 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BgParams p) {
     }
 }
 
+// can the operand's unit-stride direction be read as 16-byte vectors?  One stride is 1; a bf16 vector needs a dword-aligned address:
+// base pointer and every other stride even (K-steps and tile origins are multiples of 8)
+int bg_vec_ok(const void* ptr, int f32, int64_t s_row, int64_t s_k, int64_t b1, int64_t b2) {
+    if (s_row != 1 && s_k != 1) return 0;
+    if (f32) return (reinterpret_cast<uintptr_t>(ptr) & 3u) == 0;
+    const int64_t other = s_row == 1 ? s_k : s_row;
+    if (s_row == 1 && s_k == 1) return 0;
+    return (reinterpret_cast<uintptr_t>(ptr) & 3u) == 0 && !(other & 1) && !(b1 & 1) && !(b2 & 1);
+}
+
 }  // namespace
 
 extern "C" int nrv_bgemm(const void* A, int a_dtype, int64_t a_rs, int64_t a_cs, int64_t a_b1, int64_t a_b2,
@@ -126,6 +186,8 @@ extern "C" int nrv_bgemm(const void* A, int a_dtype, int64_t a_rs, int64_t a_cs,
     p.G2 = G2; p.M = M; p.N = N; p.K = K;
     p.tiles_m = (int)tiles_m; p.tiles_n = (int)tiles_n;
     p.alpha = alpha;
+    p.a_vec = bg_vec_ok(A, p.A.f32, a_rs, a_cs, a_b1, a_b2);
+    p.b_vec = bg_vec_ok(B, p.B.f32, b_cs, b_rs, b_b1, b_b2);
     hipLaunchKernelGGL(bgemm_kernel, dim3((unsigned)blocks), dim3(BG_THREADS), 0, static_cast<hipStream_t>(stream), p);
     NRV_CHECK_LAUNCH();
     return 0;
