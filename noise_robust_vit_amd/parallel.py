@@ -87,7 +87,9 @@ class GradReducer:
         (examples/CIFAR100.py:206-208 wraps the model in DDP): replicas start identical whatever each rank's seed was.
         `force_collectives`: issue every bucket's all-reduce even when world == 1 (a single-GPU RCCL process group
         exercises exactly the calls, stream ordering and buffer slicing of the multi-GPU step).
-        `grad_dtype`: "fp32" (default, exact mean of the ranks' fp32 gradients) or "bf16" (each rank's bucket is rounded to
+        `grad_dtype`: "fp32" (default, exact mean of the ranks' fp32 gradients; `param.grad` holds the reduced values after
+        finish_step) or "bf16" (on the HIP device the reduced means live in `grad_buffer()` = the bf16 image `flat16`, which
+        optim.FusedAdamW reads in place; `param.grad` then still shows this rank's LOCAL fp32 gradients) -- each rank's bucket is rounded to
         bf16 before the reduction: 8 significant bits per addend, relative error of the mean <= 2^-8 per element -- the size of
         the rounding the bf16 GEMM operands already carry; tests/test_parallel_gloo.py states the measured cost).
         `tail_mib`: upper bound of the last bucket in backward order (0: no cap).
