@@ -439,6 +439,7 @@ class EncoderStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta: BlockMeta, *params):
         x2, B, N, D = _as_stream(x)
+        _PENDING.clear()                    # gradients queued by a backward that raised half-way never run: drop them (and their operands)
         depth = len(params) // PARAMS_PER_LAYER
         saved = []
         cur = x2
