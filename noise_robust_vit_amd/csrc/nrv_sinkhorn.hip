@@ -27,6 +27,8 @@ namespace {
 
 using namespace nrv_attn;
 
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;   // the backward kernel's resident copy of one P0 tile
+
 constexpr int SK_THREADS = 1024;      // 16 waves: one 16-query tile each (N <= 256)
 constexpr int SK_WAVES = 16;
 constexpr int SK_TPW = 2;             // query tiles per wave of the backward kernel
@@ -315,18 +317,15 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
             out[e] = pv;
         }
     };
-    auto p0_tiles = [&](int kt, f32x4_t (&p0)[TPW]) {
-        SK_KEEP_ORDER();
-        bf16x8_t kr[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kr[ks] = row_frag_img(kimg, kt * 16, ks, lane);
-#pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) st = mfma16(kr[ks], qf[u][ks], st);
-            p0_from(st, kt, u, p0[u]);
-        }
+    // P0 is computed ONCE (in the dV phase) and kept in registers as fp16 (values in [0, 1]: 11 significant bits, everything
+    // below 6e-8 -- exp2 of less than -24 -- reads back as zero); the walk reads it through v_fma_mix_f32 (fp16 operand, fp32
+    // arithmetic).  Recomputing it instead (MFMA + v_exp_f32, which issues at a quarter of the VALU rate) in each of the 9
+    // later passes was 40 % of the kernel's VALU cycles.
+    u32x2_t P0h[TPW][NT];           // f16x4_t bit patterns
+    auto p0h = [&](int u, int kt) {
+        // opaque per use: hipcc would otherwise convert every tile back ONCE and keep the fp32 copy live (spilled)
+        asm volatile("" : "+v"(P0h[u][kt]));
+        return __builtin_bit_cast(f16x4_t, P0h[u][kt]);
     };
 
     // key-owner side: this wave's key tiles are wave + SKQ_WAVES s; the chunk rows are queries u CH .. of slot u
@@ -382,6 +381,8 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) st = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[u][ks], st);
                 p0_from(st, kt, u, p0u);
+                P0h[u][kt] = __builtin_bit_cast(u32x2_t, __builtin_convertvector(p0u, f16x4_t));
+                asm volatile("" : "+v"(P0h[u][kt]));                  // convert here, not at the first use (the fp32 tile would stay live)
                 const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
                 const float a4 = av[u][4];                                    // 0 for inactive tiles / padded queries
                 const u32x2_t pk = {pack_bf16x2(a4 * p0u[0] * b3[0], a4 * p0u[1] * b3[1]), pack_bf16x2(a4 * p0u[2] * b3[2], a4 * p0u[3] * b3[3])};
@@ -390,6 +391,9 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
             __syncthreads();
             key_owner_products(dv, img1, u);
             __syncthreads();
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) P0h[u][kt] = u32x2_t{0u, 0u};      // tile slot beyond the head: G stays finite
         }
     }
     store_key_rows(dv, 2);
@@ -423,6 +427,34 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     }
 
     SK_STAMP();           // 3: V image + G
+    // column sums of a key-tile pair (kt, kt + NT / 2) over the 16 query lanes of a DPP row, as a butterfly: after the
+    // exchange over lane bit 3 a lane keeps the tile of its half, after the one over bit 2 the element pair of its quad, and a
+    // quad reduction finishes -- 10 cross-lane adds for 8 values instead of 32, and one store per value instead of 16 lanes
+    // holding the same sum.  Lane (g, qc) ends with the sums of the keys 16 (kt + NT/2 b3) + 4 g + 2 b2 + {0, 1}.
+    const bool hi8 = (qc & 8) != 0, hi4 = (qc & 4) != 0;
+    float* colw = colpart + wave * NP + (hi8 ? 8 * NT : 0) + 4 * g + (hi4 ? 2 : 0);
+    const bool col_writer = (lane & 3) == 0;
+    auto dpp_add = [&](float keep, float send, auto ctrl_c) {
+        constexpr int ctrl = decltype(ctrl_c)::value;
+        return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), ctrl, 0xf, 0xf, false));
+    };
+    using RowRor8 = std::integral_constant<int, 0x128>;
+    using HalfMirror = std::integral_constant<int, 0x141>;
+    using QuadXor1 = std::integral_constant<int, 0xB1>;
+    using QuadXor2 = std::integral_constant<int, 0x4E>;
+    auto col_sums_pair = [&](const f32x4_t& xa, const f32x4_t& xb, int kt) {
+        float t4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4[e] = dpp_add(hi8 ? xb[e] : xa[e], hi8 ? xa[e] : xb[e], RowRor8{});
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = dpp_add(hi4 ? t4[e + 2] : t4[e], hi4 ? t4[e] : t4[e + 2], HalfMirror{});
+            v = dpp_add(v, v, QuadXor1{});
+            v = dpp_add(v, v, QuadXor2{});
+            if (col_writer) colw[kt * 16 + e] = v;
+        }
+    };
+
     // ---- walk the normalisations backwards: steps 7 (row) 6 (col) 5 (row) 4 (col) 3 (row) 2 (col) 1 (row)
     // (fully unrolled: av[][] must be indexed statically or it lands in scratch)
 #pragma unroll
@@ -434,13 +466,15 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
             for (int u = 0; u < TPW; ++u) rho[u] = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                f32x4_t p0[TPW];
-                p0_tiles(kt, p0);
+                SK_KEEP_ORDER();
                 const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bt + kt * 16 + 4 * g);
 #pragma unroll
-                for (int u = 0; u < TPW; ++u)
+                for (int u = 0; u < TPW; ++u) {
+                    const f16x4_t ph = p0h(u, kt);
+                    const f32x4_t gb = G[u][kt] * b4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rho[u] += G[u][kt][e] * p0[u][e] * b4[e];
+                    for (int e = 0; e < 4; ++e) rho[u] = __builtin_fmaf((float)ph[e], gb[e], rho[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
@@ -449,35 +483,44 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
                 r += __shfl_xor(r, 32, 64);
                 r *= av[u][t + 1];
                 const float f = ratio_or_zero(av[u][t + 1], av[u][t]);
+                const float nrf = -r * f;
+                const f32x4_t f4 = {f, f, f, f}, c4 = {nrf, nrf, nrf, nrf};
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt) G[u][kt] = (G[u][kt] - r) * f;
+                for (int kt = 0; kt < NT; ++kt) G[u][kt] = G[u][kt] * f4 + c4;              // (G - r) f
             }
         }
         if (t == 0) break;
         {   // column step with beta = b_t, beta_prev = b_{t-1}, alpha = a_t: the tiles' contributions are added before the
-            // 16-lane reduction
+            // reduction over the query lanes
+            auto col_terms = [&](int kt) {
+                f32x4_t x = {0.f, 0.f, 0.f, 0.f};                            // av = 0 for inactive tiles
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                f32x4_t p0[TPW];
-                p0_tiles(kt, p0);
+                for (int u = 0; u < TPW; ++u) {
+                    const f16x4_t ph = p0h(u, kt);
+                    const float au = av[u][t];
+                    const f32x4_t a4 = {au, au, au, au};
+                    const f32x4_t ga = G[u][kt] * a4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = 0.f;                                       // av = 0 for inactive tiles
-#pragma unroll
-                    for (int u = 0; u < TPW; ++u) x += G[u][kt][e] * av[u][t] * p0[u][e];
-                    const float v = row16_sum(x);
-                    if (qc == 0) colpart[wave * NP + kt * 16 + 4 * g + e] = v;
+                    for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf((float)ph[e], ga[e], x[e]);
                 }
+                return x;
+            };
+#pragma unroll
+            for (int kt = 0; kt < NT / 2; ++kt) {
+                SK_KEEP_ORDER();
+                const f32x4_t xa = col_terms(kt), xb = col_terms(kt + NT / 2);
+                col_sums_pair(xa, xb, kt);
             }
             __syncthreads();
             for (int j = tid; j < NP; j += SKQ_THREADS) {
                 float c = 0.f;
 #pragma unroll
                 for (int w = 0; w < SKQ_WAVES; ++w) c += colpart[w * NP + j];
-                // kap = beta_j * colsum, and the ratio beta_t / beta_{t-1} of the rescale that follows (once per column
-                // here instead of once per element in every wave)
-                kap[j] = c * bv[t * NP + j];
-                colpart[j] = ratio_or_zero(bv[t * NP + j], bv[(t - 1) * NP + j]);      // row 0 of colpart is free again: all partials were read
+                // the rescale that follows is G <- (G - beta_j colsum) * (beta_t / beta_{t-1}) = G ratio + kap: both factors once
+                // per column here instead of once per element in every wave
+                const float ratio = ratio_or_zero(bv[t * NP + j], bv[(t - 1) * NP + j]);
+                kap[j] = -c * bv[t * NP + j] * ratio;
+                colpart[j] = ratio;                                          // row 0 of colpart is free again: all partials were read
             }
             __syncthreads();
 #pragma unroll
@@ -486,7 +529,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
                 const f32x4_t k4 = *reinterpret_cast<const f32x4_t*>(kap + kt * 16 + 4 * g);
                 const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(colpart + kt * 16 + 4 * g);
 #pragma unroll
-                for (int u = 0; u < TPW; ++u) G[u][kt] = (G[u][kt] - k4) * r4;
+                for (int u = 0; u < TPW; ++u) G[u][kt] = G[u][kt] * r4 + k4;
             }
             __syncthreads();      // kap / colpart are rewritten by the next column step
         }
@@ -499,27 +542,26 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
 #pragma unroll
         for (int u = 0; u < TPW; ++u) sd[u] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4_t p0[TPW];
-            p0_tiles(kt, p0);
+        for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int u = 0; u < TPW; ++u)
+            for (int u = 0; u < TPW; ++u) {
+                const f16x4_t ph = p0h(u, kt);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sd[u] += G[u][kt][e] * p0[u][e];
-        }
+                for (int e = 0; e < 4; ++e) sd[u] = __builtin_fmaf((float)ph[e], G[u][kt][e], sd[u]);
+            }
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             sd[u] += __shfl_xor(sd[u], 16, 64);
             sd[u] += __shfl_xor(sd[u], 32, 64);
-        }
+            const float ns = -sd[u] * p.scale;
+            const f32x4_t s4 = {p.scale, p.scale, p.scale, p.scale}, n4 = {ns, ns, ns, ns};
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4_t p0[TPW];
-            p0_tiles(kt, p0);
+            for (int kt = 0; kt < NT; ++kt) {
+                const f16x4_t ph = p0h(u, kt);
+                const f32x4_t d = G[u][kt] * s4 + n4;
 #pragma unroll
-            for (int u = 0; u < TPW; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) G[u][kt][e] = p0[u][e] * (G[u][kt][e] - sd[u]) * p.scale;
+                for (int e = 0; e < 4; ++e) G[u][kt][e] = (float)ph[e] * d[e];
+            }
         }
     }
 
