@@ -260,7 +260,8 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     float* colpart = kap + NP;                                    // [SKQ_WAVES][NP]
     char* chunk = reinterpret_cast<char*>(colpart + SKQ_WAVES * NP);
     constexpr int NT = NP / 16;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;            // re-derived (opaquely) at the phase boundaries: see relane()
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     NRV_STAMP_SEQ_VARS(tid);      // phase stamps of thread 0: empty hooks in the product (csrc/nrv_dev.hpp)
 #define SK_STAMP() NRV_STAMP_SEQ()
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
         for (int t = 0; t < 3; ++t) bv[(t + 1) * NP + j] = j < N ? scal[(2 * t + 1) * N + j] : 0.f;
     }
 
-    const int g = lane >> 4, qc = lane & 15;
+    int g = lane >> 4, qc = lane & 15;
     const int nqt = (N + 15) >> 4;
     const float sc = p.scale * LOG2E;
     bool active[TPW], q_ok[TPW];
@@ -329,9 +330,20 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     };
 
     // key-owner side: this wave's key tiles are wave + SKQ_WAVES s; the chunk rows are queries u CH .. of slot u
-    const int tq = (lane & 15) >> 2, tpp = lane & 3;
-    const int chunk_rd = (4 * g + tq) * RS + tpp * 8;                        // + (32 ks + {0, 16}) RS + 32 kt
-    const int chunk_wr = (wave * 16 + qc) * RS + 8 * g;                      // + 32 kt: 4 consecutive keys of the lane's query
+    int chunk_rd = (4 * g + ((lane & 15) >> 2)) * RS + (lane & 3) * 8;       // + (32 ks + {0, 16}) RS + 32 kt
+    int chunk_wr = (wave * 16 + qc) * RS + 8 * g;                            // + 32 kt: 4 consecutive keys of the lane's query
+    // The per-lane indices and LDS offsets are cheap to derive and expensive to keep: between the phases the lane id goes
+    // through an empty asm, so everything derived from it is recomputed where it is used instead of living (or being spilled)
+    // through the walk, which needs the registers for G and P0.
+    auto relane = [&]() {
+        asm volatile("" : "+v"(lane));
+        g = lane >> 4;
+        qc = lane & 15;
+        chunk_rd = (4 * g + ((lane & 15) >> 2)) * RS + (lane & 3) * 8;
+        chunk_wr = (wave * 16 + qc) * RS + 8 * g;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) q[u] = (wave + SKQ_WAVES * u) * 16 + qc;
+    };
     auto key_owner_products = [&](f32x4_t (&acc)[TPW][4], const char* img, int u) {      // acc[s][dt] += img^T[d, q] . chunk[q, key]
         const int rows = NP - u * CH < CH ? NP - u * CH : CH;                // multiple of 32 (NP is)
 #pragma unroll
@@ -410,6 +422,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
         asm volatile("" ::: "memory");
         __syncthreads();
     }
+    relane();
     f32x4_t G[TPW][NT];             // fp32, walked back through the normalisations in place
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
@@ -431,6 +444,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     // exchange over lane bit 3 a lane keeps the tile of its half, after the one over bit 2 the element pair of its quad, and a
     // quad reduction finishes -- 10 cross-lane adds for 8 values instead of 32, and one store per value instead of 16 lanes
     // holding the same sum.  Lane (g, qc) ends with the sums of the keys 16 (kt + NT/2 b3) + 4 g + 2 b2 + {0, 1}.
+    relane();
     const bool hi8 = (qc & 8) != 0, hi4 = (qc & 4) != 0;
     float* colw = colpart + wave * NP + (hi8 ? 8 * NT : 0) + 4 * g + (hi4 ? 2 : 0);
     const bool col_writer = (lane & 3) == 0;
@@ -474,6 +488,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
                     const f32x4_t gb = G[u][kt] * b4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rho[u] = __builtin_fmaf((float)ph[e], gb[e], rho[u]);
+                    asm volatile("" : "+v"(rho[u]));
                 }
             }
 #pragma unroll
@@ -529,7 +544,10 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
                 const f32x4_t k4 = *reinterpret_cast<const f32x4_t*>(kap + kt * 16 + 4 * g);
                 const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(colpart + kt * 16 + 4 * g);
 #pragma unroll
-                for (int u = 0; u < TPW; ++u) G[u][kt] = G[u][kt] * r4 + k4;
+                for (int u = 0; u < TPW; ++u) {
+                    G[u][kt] = G[u][kt] * r4 + k4;
+                    asm volatile("" : "+v"(G[u][kt]));       // finished HERE: hipcc otherwise issues all 2 NT vector loads first (112 registers)
+                }
             }
             __syncthreads();      // kap / colpart are rewritten by the next column step
         }
@@ -566,6 +584,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     }
 
     SK_STAMP();           // 8: softmax backward
+    relane();
     // ---- dQ = dS K
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
