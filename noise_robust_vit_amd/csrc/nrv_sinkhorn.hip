@@ -55,6 +55,29 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ float inv_or_zero(float x) { return x > 0.f ? 1.0f / x : 0.f; }
 __device__ __forceinline__ float ratio_or_zero(float num, float den) { return den > 0.f ? num / den : 0.f; }
 
+// Column sums of a key-tile pair (kt, kt + NT / 2) over the 16 query lanes of a DPP row, as a butterfly: after the exchange
+// over lane bit 3 a lane keeps the tile of its half, after the one over bit 2 the element pair of its quad, and a quad
+// reduction finishes -- 10 cross-lane adds for 8 values instead of 32, and one store per value instead of 16 lanes holding the
+// same sum.  Lane (g, qc) ends with the sums of the keys 16 (kt + NT/2 b3) + 4 g + 2 b2 + {0, 1}, b3 = hi8, b2 = hi4:
+// dst = partial-sum row of the wave + 16 kt + that lane offset; the lanes with (lane & 3) == 0 write.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float keep, float send) {
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void col_sums_pair(const f32x4_t xa, const f32x4_t xb, float* dst, bool hi8, bool hi4, bool writer) {
+    constexpr int ROW_ROR8 = 0x128, HALF_MIRROR = 0x141, QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E;
+    float t4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t4[e] = dpp_add<ROW_ROR8>(hi8 ? xb[e] : xa[e], hi8 ? xa[e] : xb[e]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float v = dpp_add<HALF_MIRROR>(hi4 ? t4[e + 2] : t4[e], hi4 ? t4[e] : t4[e + 2]);
+        v = dpp_add<QUAD_XOR1>(v, v);
+        v = dpp_add<QUAD_XOR2>(v, v);
+        if (writer) dst[e] = v;
+    }
+}
+
 // S^T tiles of one query tile -> P0 (normalised softmax, fp32); returns via p0[]; padded keys/queries are zero
 template <int NP>
 __device__ __forceinline__ void softmax_tile(const char* kimg, const bf16x8_t (&qf)[2], f32x4_t (&p0)[NP / 16],
@@ -149,18 +172,17 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_fwd_kernel(const SinkPara
     }
     if (q_ok && g == 0) p.lse[(long long)bh * N + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
 
+    const bool hi8 = (qc & 8) != 0, hi4 = (qc & 4) != 0;
+    float* colw = colpart + wave * NP + (hi8 ? NP / 2 : 0) + 4 * g + (hi4 ? 2 : 0);
     float a = 1.f;
 #pragma unroll 1
     for (int t = 0; t < 3; ++t) {
         a = inv_or_zero(row_dot<NP>(p0, bvec, lane));                      // P /= rowsum(P)
         if (q_ok && g == 0) scal[(2 * t) * N + q] = a;
+        const float aa = active ? a : 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NP / 16; ++kt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = row16_sum(active ? a * p0[kt][e] : 0.f);
-                if (qc == 0) colpart[wave * NP + kt * 16 + 4 * g + e] = v;
-            }
+        for (int kt = 0; kt < NP / 32; ++kt)
+            col_sums_pair(p0[kt] * aa, p0[kt + NP / 32] * aa, colw + kt * 16, hi8, hi4, (lane & 3) == 0);
         __syncthreads();
         for (int j = tid; j < NP; j += SK_THREADS) {                        // P /= colsum(P)
             float c = 0.f;
@@ -440,34 +462,10 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     }
 
     SK_STAMP();           // 3: V image + G
-    // column sums of a key-tile pair (kt, kt + NT / 2) over the 16 query lanes of a DPP row, as a butterfly: after the
-    // exchange over lane bit 3 a lane keeps the tile of its half, after the one over bit 2 the element pair of its quad, and a
-    // quad reduction finishes -- 10 cross-lane adds for 8 values instead of 32, and one store per value instead of 16 lanes
-    // holding the same sum.  Lane (g, qc) ends with the sums of the keys 16 (kt + NT/2 b3) + 4 g + 2 b2 + {0, 1}.
     relane();
     const bool hi8 = (qc & 8) != 0, hi4 = (qc & 4) != 0;
     float* colw = colpart + wave * NP + (hi8 ? 8 * NT : 0) + 4 * g + (hi4 ? 2 : 0);
     const bool col_writer = (lane & 3) == 0;
-    auto dpp_add = [&](float keep, float send, auto ctrl_c) {
-        constexpr int ctrl = decltype(ctrl_c)::value;
-        return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), ctrl, 0xf, 0xf, false));
-    };
-    using RowRor8 = std::integral_constant<int, 0x128>;
-    using HalfMirror = std::integral_constant<int, 0x141>;
-    using QuadXor1 = std::integral_constant<int, 0xB1>;
-    using QuadXor2 = std::integral_constant<int, 0x4E>;
-    auto col_sums_pair = [&](const f32x4_t& xa, const f32x4_t& xb, int kt) {
-        float t4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t4[e] = dpp_add(hi8 ? xb[e] : xa[e], hi8 ? xa[e] : xb[e], RowRor8{});
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float v = dpp_add(hi4 ? t4[e + 2] : t4[e], hi4 ? t4[e] : t4[e + 2], HalfMirror{});
-            v = dpp_add(v, v, QuadXor1{});
-            v = dpp_add(v, v, QuadXor2{});
-            if (col_writer) colw[kt * 16 + e] = v;
-        }
-    };
 
     // ---- walk the normalisations backwards: steps 7 (row) 6 (col) 5 (row) 4 (col) 3 (row) 2 (col) 1 (row)
     // (fully unrolled: av[][] must be indexed statically or it lands in scratch)
@@ -524,7 +522,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
             for (int kt = 0; kt < NT / 2; ++kt) {
                 SK_KEEP_ORDER();
                 const f32x4_t xa = col_terms(kt), xb = col_terms(kt + NT / 2);
-                col_sums_pair(xa, xb, kt);
+                col_sums_pair(xa, xb, colw + kt * 16, hi8, hi4, col_writer);
             }
             __syncthreads();
             for (int j = tid; j < NP; j += SKQ_THREADS) {
