@@ -13,6 +13,7 @@
 #define NRV_WACC_FLUSH(nwaves, wave, lane)
 #define NRV_STAMP_SEQ_VARS(tid)        // sequential phase stamps of one thread, written as they are taken
 #define NRV_STAMP_SEQ()
+#define NRV_STAMP_SEQ_RESET()          // persistent kernels: the sequence starts again with every unit of work
 #define NRV_TILE_STAMP_VARS(wave)      // persistent kernels: wall-clock stamps of wave 0 along its tile sequence
 #define NRV_TILE_STAMP()
 #define NRV_TUNE_NT_TILE(choice) (choice)      // tile-height override of the instrumented header (tools/tile_sweep.py)

@@ -274,9 +274,9 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     constexpr bool THREE = L::THREE;
     static_assert((RS / 4) % 16 == 8, "chunk rows must be 8 dwords mod 16 apart");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kimg = smem;                                            // row + transposed reads
-    char* img1 = smem + NP * 128;                                 // dO, then (two slots: V, then) Q
-    char* vimg = smem + (THREE ? 2 : 1) * NP * 128;               // V: its own slot when there is room
+    char* const slot0 = smem;
+    char* const img1 = smem + NP * 128;                           // dO, then (two slots: V, then) Q
+    char* const slot2 = smem + (THREE ? 2 : 1) * NP * 128;        // three slots: K and V alternate between slot 0 and slot 2 from head to head
     float* bv = reinterpret_cast<float*>(smem + L::IMAGES * NP * 128);    // [4][NP]: b0 = 1, b1, b2, b3
     float* kap = bv + 4 * NP;                                     // [NP] column correction of the current step
     float* colpart = kap + NP;                                    // [SKQ_WAVES][NP]
@@ -287,48 +287,90 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     NRV_STAMP_SEQ_VARS(tid);      // phase stamps of thread 0: empty hooks in the product (csrc/nrv_dev.hpp)
 #define SK_STAMP() NRV_STAMP_SEQ()
-    SK_STAMP();
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N;
+    const int nbh = p.B * p.H;
     const long long ldq = 3ll * p.H * DH, ldo = (long long)p.H * DH;
+    const int nqt = (N + 15) >> 4;
+    const float sc = p.scale * LOG2E;
+    int g = lane >> 4, qc = lane & 15;
+    bool active[TPW];
+    int q[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        active[u] = wave + SKQ_WAVES * u < nqt;
+        q[u] = (wave + SKQ_WAVES * u) * 16 + qc;
+    }
+    auto qbase_of = [&](int bh_) {
+        const int b_ = bh_ / p.H, h_ = bh_ - b_ * p.H;
+        return p.qkv + (long long)b_ * N * ldq + h_ * DH;
+    };
+    // One workgroup per CU walks the heads blockIdx.x, + gridDim.x, ... (three image slots: otherwise the grid is the head count).
+    // What a head needs before it can start -- its K image, Q fragments and LSE -- is requested during the previous head:
+    // K into the slot its V image has left (after G is built), the per-lane values into registers during the dK phase; the
+    // other operands are requested at the top and land under the P0 computation.
+    bf16x8_t qf_n[TPW][2];
+    float lse2_n[TPW];
+    auto request_q_lse = [&](int bh_) {
+        const bf16_t* qb = qbase_of(bh_);
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const bool ok = active[u] && q[u] < N;
+            const int qr = q[u] < N ? q[u] : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf_n[u][ks] = load_frag_global(qb + (long long)qr * ldq + ks * 32 + g * 8);
+            lse2_n[u] = ok ? p.lse[(long long)bh_ * N + qr] * LOG2E : INFINITY;      // exp2(s - inf) = 0: padded queries need no mask
+        }
+    };
+    int bh = blockIdx.x;            // < nbh (host)
+    dma_image<NP, SKQ_WAVES>(slot0, qbase_of(bh) + p.H * DH, ldq, N, wave, lane);
+    request_q_lse(bh);
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) through the builtin: hipcc's own counting stays exact
+    asm volatile("" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; bh < nbh; ++it, bh += gridDim.x) {
+    NRV_STAMP_SEQ_RESET();
+    SK_STAMP();
+    asm volatile("" : "+v"(lane));
+    g = lane >> 4;
+    qc = lane & 15;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) q[u] = (wave + SKQ_WAVES * u) * 16 + qc;
+    const bool odd = THREE && (it & 1);
+    char* const kimg = odd ? slot2 : slot0;                       // row + transposed reads
+    char* const vimg = odd ? slot0 : slot2;                       // two slots: img1 (V follows dO there)
+    const bool more = bh + (int)gridDim.x < nbh;
+    const int b = bh / p.H, h = bh - b * p.H;
     const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
     const bf16_t* dobase = p.dout + (long long)b * N * ldo + h * DH;
     const float* scal = p.scal + (long long)bh * 7 * N;
-    dma_image<NP, SKQ_WAVES>(kimg, qbase + p.H * DH, ldq, N, wave, lane);
-    dma_image<NP, SKQ_WAVES>(img1, dobase, ldo, N, wave, lane);
-    if (THREE) dma_image<NP, SKQ_WAVES>(vimg, qbase + 2 * p.H * DH, ldq, N, wave, lane);
-    for (int j = tid; j < NP; j += SKQ_THREADS) {
-        bv[j] = j < N ? 1.0f : 0.f;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) bv[(t + 1) * NP + j] = j < N ? scal[(2 * t + 1) * N + j] : 0.f;
-    }
-
-    int g = lane >> 4, qc = lane & 15;
-    const int nqt = (N + 15) >> 4;
-    const float sc = p.scale * LOG2E;
-    bool active[TPW], q_ok[TPW];
-    int q[TPW];
+    bool q_ok[TPW];
     float av[TPW][5];               // a0 = 1, a1 .. a4 of the lane's query, per tile
     float lse2[TPW];
-    bf16x8_t qf[TPW][2];            // Q fragments: kept for the P0 recomputation
+    bf16x8_t qf[TPW][2];            // Q fragments (P0 = softmax(Q K^T))
+    bf16x8_t dof[TPW][2];           // dO fragments (G = dO V^T): requested here, used after the dV phase
+    float sb[3] = {0.f, 0.f, 0.f};  // b1 .. b3 of column tid (SKQ_THREADS >= NP)
+    static_assert(SKQ_THREADS >= NP, "one column per thread");
+    if (tid < N) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) sb[t] = scal[(2 * t + 1) * N + tid];
+    }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-        const int tile = wave + SKQ_WAVES * u;
-        active[u] = tile < nqt;
-        q[u] = tile * 16 + qc;
         q_ok[u] = active[u] && q[u] < N;
         const int qr = q[u] < N ? q[u] : N - 1;
         av[u][0] = q_ok[u] ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) av[u][t + 1] = q_ok[u] ? scal[(2 * t) * N + qr] : 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[u][ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
-        lse2[u] = q_ok[u] ? p.lse[(long long)bh * N + qr] * LOG2E : INFINITY;      // exp2(s - inf) = 0: padded queries need no mask
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[u][ks] = qf_n[u][ks];
+            dof[u][ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
+        }
+        lse2[u] = lse2_n[u];
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the images have landed (through the builtin: hipcc's own counting stays exact)
-    asm volatile("" ::: "memory");
-    __syncthreads();
-    SK_STAMP();           // 1: images + vectors loaded
+    dma_image<NP, SKQ_WAVES>(img1, dobase, ldo, N, wave, lane);
+    if (THREE) dma_image<NP, SKQ_WAVES>(vimg, qbase + 2 * p.H * DH, ldq, N, wave, lane);
     // P0 of key tile kt (zero for padded keys / queries): for all tile slots of the wave, or for one
     auto p0_from = [&](const f32x4_t& st, int kt, int u, f32x4_t& out) {
 #pragma unroll
@@ -368,19 +410,32 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     };
     auto key_owner_products = [&](f32x4_t (&acc)[TPW][4], const char* img, int u) {      // acc[s][dt] += img^T[d, q] . chunk[q, key]
         const int rows = NP - u * CH < CH ? NP - u * CH : CH;                // multiple of 32 (NP is)
+        // per 32-query step: the four image fragments (shared by the wave's key tiles) and one chunk fragment per key tile,
+        // read one step ahead of the MFMAs that consume them
+        bf16x8_t imf[2][4], cf[2][TPW];
+        auto fetch = [&](int ks, int buf) {
 #pragma unroll
-        for (int s = 0; s < TPW; ++s) {
-            const int ktw = wave + SKQ_WAVES * s;
-            if (ktw < NT) {
+            for (int dt = 0; dt < 4; ++dt) imf[buf][dt] = tr_frag_img(img, u * CH + ks * 32, dt, lane);
 #pragma unroll
-                for (int ks = 0; ks < CH / 32; ++ks) {
-                    if (ks * 32 < rows) {
-                        SK_KEEP_ORDER();
-                        const char* a0 = chunk + chunk_rd + ks * 32 * RS + ktw * 32;
-                        const bf16x8_t cf = cat4(lds_read_tr16_b64(a0), lds_read_tr16_b64(a0 + 16 * RS));
+            for (int s = 0; s < TPW; ++s) {
+                const int ktw = wave + SKQ_WAVES * s;
+                if (ktw < NT) {
+                    const char* a0 = chunk + chunk_rd + ks * 32 * RS + ktw * 32;
+                    cf[buf][s] = cat4(lds_read_tr16_b64(a0), lds_read_tr16_b64(a0 + 16 * RS));
+                }
+            }
+        };
+        fetch(0, 0);
 #pragma unroll
-                        for (int dt = 0; dt < 4; ++dt)
-                            acc[s][dt] = mfma16(tr_frag_img(img, u * CH + ks * 32, dt, lane), cf, acc[s][dt]);
+        for (int ks = 0; ks < CH / 32; ++ks) {
+            if (ks * 32 < rows) {
+                SK_KEEP_ORDER();
+                if ((ks + 1) * 32 < rows) fetch(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int s = 0; s < TPW; ++s) {
+                    if (wave + SKQ_WAVES * s < NT) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) acc[s][dt] = mfma16(imf[ks & 1][dt], cf[ks & 1][s], acc[s][dt]);
                     }
                 }
             }
@@ -398,6 +453,38 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
         }
     };
 
+    // ---- P0 of both tile slots, once: the K fragments of a key tile serve both slots and are read one tile ahead
+    {
+        bf16x8_t kr[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kr[0][ks] = row_frag_img(kimg, 0, ks, lane);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            SK_KEEP_ORDER();
+            if (kt + 1 < NT) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) kr[(kt + 1) & 1][ks] = row_frag_img(kimg, (kt + 1) * 16, ks, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, p0u;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) st = mfma16(kr[kt & 1][ks], qf[u][ks], st);
+                p0_from(st, kt, u, p0u);              // zero for the queries of a tile slot beyond the head (lse2 = inf)
+                P0h[u][kt] = __builtin_bit_cast(u32x2_t, __builtin_convertvector(p0u, f16x4_t));
+                asm volatile("" : "+v"(P0h[u][kt]));                  // convert here, not at the first use (the fp32 tile would stay live)
+            }
+        }
+    }
+    SK_STAMP();           // 1: requests + P0
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // dO / V images and the per-lane values of this head (requested before P0) have landed
+    asm volatile("" ::: "memory");
+    if (tid < NP) {
+        bv[tid] = tid < N ? 1.0f : 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bv[(t + 1) * NP + tid] = sb[t];
+    }
+    __syncthreads();
     // ---- dV = P7^T dO,  P7 = a4 P0 b3
     {
     f32x4_t dv[TPW][4];
@@ -411,23 +498,16 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 SK_KEEP_ORDER();
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, p0u;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) st = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[u][ks], st);
-                p0_from(st, kt, u, p0u);
-                P0h[u][kt] = __builtin_bit_cast(u32x2_t, __builtin_convertvector(p0u, f16x4_t));
-                asm volatile("" : "+v"(P0h[u][kt]));                  // convert here, not at the first use (the fp32 tile would stay live)
+                const f16x4_t ph = p0h(u, kt);
                 const f32x4_t b3 = *reinterpret_cast<const f32x4_t*>(bv + 3 * NP + kt * 16 + 4 * g);
                 const float a4 = av[u][4];                                    // 0 for inactive tiles / padded queries
-                const u32x2_t pk = {pack_bf16x2(a4 * p0u[0] * b3[0], a4 * p0u[1] * b3[1]), pack_bf16x2(a4 * p0u[2] * b3[2], a4 * p0u[3] * b3[3])};
+                const f32x4_t ab = b3 * f32x4_t{a4, a4, a4, a4};
+                const u32x2_t pk = {pack_bf16x2((float)ph[0] * ab[0], (float)ph[1] * ab[1]), pack_bf16x2((float)ph[2] * ab[2], (float)ph[3] * ab[3])};
                 *reinterpret_cast<u32x2_t*>(chunk + chunk_wr + kt * 32) = pk;
             }
             __syncthreads();
             key_owner_products(dv, img1, u);
             __syncthreads();
-        } else {
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) P0h[u][kt] = u32x2_t{0u, 0u};      // tile slot beyond the head: G stays finite
         }
     }
     store_key_rows(dv, 2);
@@ -446,18 +526,23 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     }
     relane();
     f32x4_t G[TPW][NT];             // fp32, walked back through the normalisations in place
+    {
+        bf16x8_t vr[2][2];              // V fragments of a key tile: both tile slots, one tile ahead
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        const int qr = q[u] < N ? q[u] : N - 1;
-        bf16x8_t dof[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) dof[ks] = load_frag_global(dobase + (long long)qr * ldo + ks * 32 + g * 8);
+        for (int ks = 0; ks < 2; ++ks) vr[0][ks] = row_frag_img(vimg, 0, ks, lane);
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             SK_KEEP_ORDER();
-            G[u][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (kt + 1 < NT) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) G[u][kt] = mfma16(row_frag_img(vimg, kt * 16, ks, lane), dof[ks], G[u][kt]);
+                for (int ks = 0; ks < 2; ++ks) vr[(kt + 1) & 1][ks] = row_frag_img(vimg, (kt + 1) * 16, ks, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                G[u][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) G[u][kt] = mfma16(vr[kt & 1][ks], dof[u][ks], G[u][kt]);
+            }
         }
     }
 
@@ -525,6 +610,8 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
                 col_sums_pair(xa, xb, colw + kt * 16, hi8, hi4, col_writer);
             }
             __syncthreads();
+            if (THREE && t == 3 && more)      // every wave has built its G: the V slot takes the next head's K image
+                dma_image<NP, SKQ_WAVES>(vimg, qbase_of(bh + gridDim.x) + p.H * DH, ldq, N, wave, lane);
             for (int j = tid; j < NP; j += SKQ_THREADS) {
                 float c = 0.f;
 #pragma unroll
@@ -583,24 +670,36 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
 
     SK_STAMP();           // 8: softmax backward
     relane();
-    // ---- dQ = dS K
+    // ---- dQ = dS K: the K fragments of a 32-key step serve both tile slots and are read one step ahead
+    {
+        f32x4_t dq[TPW][4];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        if (active[u]) {
-            f32x4_t dq[4];
+        for (int u = 0; u < TPW; ++u)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < 4; ++dt) dq[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        bf16x8_t kf[2][4];
 #pragma unroll
-            for (int kk = 0; kk < NP / 32; ++kk) {
-                SK_KEEP_ORDER();
+        for (int dt = 0; dt < 4; ++dt) kf[0][dt] = tr_frag_img(kimg, 0, dt, lane);
+#pragma unroll
+        for (int kk = 0; kk < NP / 32; ++kk) {
+            SK_KEEP_ORDER();
+            if (kk + 1 < NP / 32) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) kf[(kk + 1) & 1][dt] = tr_frag_img(kimg, (kk + 1) * 32, dt, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
                 const bf16x8_t dsf = pack_frag(G[u][2 * kk], G[u][2 * kk + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag_img(kimg, kk * 32, dt, lane), dsf, dq[dt]);
+                for (int dt = 0; dt < 4; ++dt) dq[u][dt] = mfma16(kf[kk & 1][dt], dsf, dq[u][dt]);
             }
-            if (q[u] < N) {
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            if (active[u] && q[u] < N) {
                 bf16_t* dst = p.dqkv + ((long long)b * N + q[u]) * ldq + h * DH + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, dq[dt]);
+                for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, dq[u][dt]);
             }
         }
     }
@@ -624,17 +723,29 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
                 const u32x2_t pk = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
                 *reinterpret_cast<u32x2_t*>(chunk + chunk_wr + kt * 32) = pk;
             }
+            if (u == 0) request_q_lse(more ? bh + (int)gridDim.x : bh);       // unconditional: qf_n / lse2_n are dead through the rest of the loop body
             __syncthreads();          // also orders the Q image stores (u == 0) before the transposed reads
             key_owner_products(dk, img1, u);
             __syncthreads();
         }
     }
     store_key_rows(dk, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // the next head's Q fragments / LSE (and its K image: waited for above, published by the barriers)
+    asm volatile("" ::: "memory");
     SK_STAMP();           // 10: dK phase
+    }
 #undef SK_STAMP
 }
 
 int np_of(int N) { return (N + 31) / 32 * 32; }
+int sk_cus() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
 
 template <int NP>
 int launch_sk_fwd(const SinkParams& p, hipStream_t s) {
@@ -654,7 +765,10 @@ int launch_sk_bwd(const SinkParams& p, hipStream_t s) {
     static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_kernel<NP, TPW>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != 0) return attr;
-    hipLaunchKernelGGL((sinkhorn_bwd_kernel<NP, TPW>), dim3(p.B * p.H), dim3(1024 / TPW), lds, s, p);
+    // three image slots: one workgroup per CU walks the heads (the next head's operands arrive during the current one)
+    const int heads = p.B * p.H;
+    const int grid = SkBwdLds<NP, TPW>::THREE && heads > sk_cus() ? sk_cus() : heads;
+    hipLaunchKernelGGL((sinkhorn_bwd_kernel<NP, TPW>), dim3(grid), dim3(1024 / TPW), lds, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }

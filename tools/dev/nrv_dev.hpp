@@ -44,6 +44,7 @@ extern "C" int NRV_DEV_CAT(nrv_dev_read_stamps_, NRV_DEV_TU)(unsigned long long*
 #define NRV_WACC_FLUSH(nwaves, wave, lane)
 #define NRV_STAMP_SEQ_VARS(tid)
 #define NRV_STAMP_SEQ()
+#define NRV_STAMP_SEQ_RESET()
 #define NRV_TILE_STAMP_VARS(tid)
 #define NRV_TILE_STAMP()
 #else
@@ -80,6 +81,7 @@ extern "C" int NRV_DEV_CAT(nrv_dev_read_stamps_, NRV_DEV_TU)(unsigned long long*
         if (nrv_sq_on_) nrv_dev_buf[(unsigned long long)blockIdx.x * 16 + nrv_sq_i_] = __builtin_amdgcn_s_memtime();    \
         ++nrv_sq_i_;                                                                                                    \
     } while (0)
+#define NRV_STAMP_SEQ_RESET() do { nrv_sq_i_ = 0; } while (0)
 #endif
 // tile stamps (persistent kernels): buf[2^20 + 32 * blockIdx.x + k] = s_memrealtime (100 MHz) of the k-th NRV_TILE_STAMP() of wave 0, k < 32.
 // `wave` is wave-uniform (readfirstlane) and all 64 lanes store the same value: a thread-0 branch in the tile loop made hipcc treat

@@ -26,10 +26,11 @@ torch.cuda.synchronize()
 buf = np.zeros(B * H * 16, dtype=np.uint64)
 assert lib.nrv_dev_read_stamps_sinkhorn(buf.ctypes.data, buf.size) == 0
 st = torch.from_numpy(buf.astype(np.int64)).view(B * H, 16)
-names = ["images K/dO + vectors", "dV phase (P7 -> chunk -> MFMA)", "V image + G init", "t=3 row+col", "t=2 row+col", "t=1 row+col", "t=0 row",
-         "softmax backward", "dQ", "Q image + dK phase"]
+st = st[st[:, 10] > 0]          # persistent kernel: one row per workgroup (its last head)
+names = ["requests + P0", "wait + vectors + dV phase (P7 -> chunk -> MFMA)", "G init", "t=3 row+col", "t=2 row+col", "t=1 row+col", "t=0 row",
+         "softmax backward", "dQ", "dK phase + next head's requests"]
 tot = (st[:, 10] - st[:, 0]).double()
-print(f"N={N}: workgroup total median {tot.median().item():.0f} cycles")
+print(f"N={N}: {st.shape[0]} workgroups, head total median {tot.median().item():.0f} cycles")
 for i, n in enumerate(names):
     d = (st[:, i + 1] - st[:, i]).double()
-    print(f"  {n:34s} {d.median().item():8.0f} cycles  {100 * d.median().item() / tot.median().item():5.1f} %")
+    print(f"  {n:48s} {d.median().item():8.0f} cycles  {100 * d.median().item() / tot.median().item():5.1f} %")
