@@ -134,84 +134,146 @@ __device__ __forceinline__ float row_dot(const f32x4_t (&p0)[NP / 16], const flo
     return r;
 }
 
+// LDS-DMA of one [N x 64] bf16 head slice (row stride ld elements) into a row image with the img_off swizzle, or (VIMG) the
+// vimg_off swizzle of the forward's V image; the swizzle is applied to the SOURCE chunk: the LDS side of a DMA instruction is
+// lane-linear.  Rows >= N read as zero.  Asynchronous: vmcnt.
+template <int NP, int NWAVES, bool VIMG = false>
+__device__ __forceinline__ void dma_image(char* img, const bf16_t* src, long long ld, int N, int wave_u, int lane) {
+    // the head's base address is uniform but comes out of an integer division (VALU): pin it to scalar registers, the
+    // descriptor of the DMA must live in SGPRs
+    const unsigned long long a = reinterpret_cast<unsigned long long>(src);
+    const unsigned a_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));      // the builtin returns int: go through
+    const unsigned a_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);              // unsigned before widening
+    const unsigned long long au = ((unsigned long long)a_hi << 32) | (unsigned long long)a_lo;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const bf16_t*>(au), 0x7fffffffull);
+    constexpr int NI = NP / 8;
+#pragma unroll
+    for (int i = 0; i < (NI + NWAVES - 1) / NWAVES; ++i) {
+        const int j = wave_u + NWAVES * i;
+        if (j < NI) {                                          // wave-uniform
+            const int r = 8 * j + (lane >> 3), pos = lane & 7;
+            const int c = VIMG ? ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1)) : (pos ^ ((r >> 1) & 7));
+            dma16(rs, img + j * 1024, r < N ? (unsigned)(r * ld * 2 + c * 16) : NRV_OOB);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+// One workgroup per CU walks the heads blockIdx.x, + gridDim.x, ...: the K / V images of the next head are requested (LDS-DMA
+// into the other image pair) and its Q fragments loaded while the current head is computed.
+template <int NP>
+struct SkFwdLds {
+    static constexpr int IMG = 2 * NP * 128;                        // K image + V image
+    static constexpr int VEC = (2 + SK_WAVES) * NP * 4;             // b vector (two: heads alternate) + the waves' partial column sums
+    static constexpr bool TWO = 2 * IMG + VEC <= 160 * 1024;        // room for the next head's images
+    static constexpr int BYTES = (TWO ? 2 : 1) * IMG + VEC;
+};
+
 template <int NP>
 __global__ __launch_bounds__(SK_THREADS) void sinkhorn_fwd_kernel(const SinkParams p) {
+    using L = SkFwdLds<NP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kimg = smem;
-    char* vimg = smem + NP * 128;
-    float* bvec = reinterpret_cast<float*>(smem + 2 * NP * 128);
-    float* colpart = bvec + NP;                                  // [SK_WAVES][NP]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    float* bvecs = reinterpret_cast<float*>(smem + (L::TWO ? 2 : 1) * L::IMG);      // [2][NP]
+    float* colpart = bvecs + 2 * NP;                             // [SK_WAVES][NP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = p.N;
+    const int nbh = p.B * p.H;
     const long long ldq = 3ll * p.H * DH;
-    const bf16_t* qbase = p.qkv + (long long)b * N * ldq + h * DH;
-    load_image<NP, false, SK_THREADS>(kimg, qbase + p.H * DH, ldq, N, tid);
-    load_image<NP, true, SK_THREADS>(vimg, qbase + 2 * p.H * DH, ldq, N, tid);
-    for (int j = tid; j < NP; j += SK_THREADS) bvec[j] = 1.0f;
-    __syncthreads();
-
     const int g = lane >> 4, qc = lane & 15;
     const int nqt = (N + 15) >> 4;
-    const bool active = wave < nqt;
+    const bool active = wave < nqt;                              // a wave beyond the head's query tiles only keeps the barriers
     const int q = wave * 16 + qc;
     const bool q_ok = active && q < N;
     const int qr = q < N ? q : N - 1;
-    float* scal = p.scal + (long long)bh * 7 * N;
-
-    f32x4_t p0[NP / 16];
-    float m = 0.f, l = 1.f;
-    {
-        bf16x8_t qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = load_frag_global(qbase + (long long)qr * ldq + ks * 32 + g * 8);
-        softmax_tile<NP>(kimg, qf, p0, N, q_ok, p.scale * LOG2E, lane, m, l);
-    }
-    if (q_ok && g == 0) p.lse[(long long)bh * N + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
-
     const bool hi8 = (qc & 8) != 0, hi4 = (qc & 4) != 0;
     float* colw = colpart + wave * NP + (hi8 ? NP / 2 : 0) + 4 * g + (hi4 ? 2 : 0);
-    float a = 1.f;
+    auto qbase_of = [&](int bh_) {
+        const int b_ = bh_ / p.H, h_ = bh_ - b_ * p.H;
+        return p.qkv + (long long)b_ * N * ldq + h_ * DH;
+    };
+    bf16x8_t qf_n[2];
+    auto request = [&](int bh_, int buf) {
+        const bf16_t* qb = qbase_of(bh_);
+        dma_image<NP, SK_WAVES>(smem + buf * L::IMG, qb + p.H * DH, ldq, N, wave, lane);
+        dma_image<NP, SK_WAVES, true>(smem + buf * L::IMG + NP * 128, qb + 2 * p.H * DH, ldq, N, wave, lane);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf_n[ks] = load_frag_global(qb + (long long)qr * ldq + ks * 32 + g * 8);
+    };
+    int bh = blockIdx.x;            // < nbh (host)
+    request(bh, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0) through the builtin: hipcc's own counting stays exact
+    asm volatile("" ::: "memory");
 #pragma unroll 1
-    for (int t = 0; t < 3; ++t) {
-        a = inv_or_zero(row_dot<NP>(p0, bvec, lane));                      // P /= rowsum(P)
-        if (q_ok && g == 0) scal[(2 * t) * N + q] = a;
-        const float aa = active ? a : 0.f;
+    for (int it = 0; bh < nbh; ++it, bh += gridDim.x) {
+        const int cur = L::TWO ? (it & 1) : 0;
+        const char* kimg = smem + cur * L::IMG;
+        const char* vimg = kimg + NP * 128;
+        float* bvec = bvecs + (it & 1) * NP;                     // the slower waves may still read the previous head's vector
+        const int b = bh / p.H, h = bh - b * p.H;
+        float* scal = p.scal + (long long)bh * 7 * N;
+        for (int j = tid; j < NP; j += SK_THREADS) bvec[j] = 1.0f;
+        bf16x8_t qf[2];
 #pragma unroll
-        for (int kt = 0; kt < NP / 32; ++kt)
-            col_sums_pair(p0[kt] * aa, p0[kt + NP / 32] * aa, colw + kt * 16, hi8, hi4, (lane & 3) == 0);
-        __syncthreads();
-        for (int j = tid; j < NP; j += SK_THREADS) {                        // P /= colsum(P)
-            float c = 0.f;
-            for (int w = 0; w < nqt; ++w) c += colpart[w * NP + j];
-            const float bn = inv_or_zero(c);
-            bvec[j] = bn;
-            if (j < N) scal[(2 * t + 1) * N + j] = bn;
-        }
-        __syncthreads();
-    }
-    a = inv_or_zero(row_dot<NP>(p0, bvec, lane));                          // final P /= rowsum(P)
-    if (q_ok && g == 0) scal[6 * N + q] = a;
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = qf_n[ks];
+        __syncthreads();                           // this head's images (every wave waited for its parts below); every wave has left the previous head
+        const bool more = bh + (int)gridDim.x < nbh;
+        if (L::TWO) request(more ? bh + (int)gridDim.x : bh, cur ^ 1);
 
-    if (active) {
-        f32x4_t o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < NP / 32; ++kk) {
-            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bvec + kk * 32 + 4 * g);
-            const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(bvec + kk * 32 + 16 + 4 * g);
-            const bf16x8_t pf = pack_frag(p0[2 * kk] * b0 * a, p0[2 * kk + 1] * b1 * a);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag_vimg(vimg, kk * 32, dt, lane), pf, o[dt]);
+        f32x4_t p0[NP / 16];
+        float a = 1.f;
+        if (active) {
+            float m = 0.f, l = 1.f;
+            softmax_tile<NP>(kimg, qf, p0, N, q_ok, p.scale * LOG2E, lane, m, l);
+            if (q_ok && g == 0) p.lse[(long long)bh * N + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
         }
-        if (q < N) {
-            bf16_t* dst = p.o + ((long long)b * N + q) * (p.H * DH) + h * DH + 4 * g;
+#pragma unroll 1
+        for (int t = 0; t < 3; ++t) {
+            if (active) {
+                a = inv_or_zero(row_dot<NP>(p0, bvec, lane));                  // P /= rowsum(P)
+                if (q_ok && g == 0) scal[(2 * t) * N + q] = a;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, o[dt]);
+                for (int kt = 0; kt < NP / 32; ++kt)
+                    col_sums_pair(p0[kt] * a, p0[kt + NP / 32] * a, colw + kt * 16, hi8, hi4, (lane & 3) == 0);
+            }
+            __syncthreads();
+            for (int j = tid; j < NP; j += SK_THREADS) {                        // P /= colsum(P)
+                float c = 0.f;
+                for (int w = 0; w < nqt; ++w) c += colpart[w * NP + j];
+                const float bn = inv_or_zero(c);
+                bvec[j] = bn;
+                if (j < N) scal[(2 * t + 1) * N + j] = bn;
+            }
+            __syncthreads();
+        }
+        // the next head's images and Q fragments were requested a head ago: waiting for them HERE, before the output stores,
+        // keeps the store latency off the next head's start
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        if (active) {
+            a = inv_or_zero(row_dot<NP>(p0, bvec, lane));                      // final P /= rowsum(P)
+            if (q_ok && g == 0) scal[6 * N + q] = a;
+            f32x4_t o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NP / 32; ++kk) {
+                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bvec + kk * 32 + 4 * g);
+                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(bvec + kk * 32 + 16 + 4 * g);
+                const bf16x8_t pf = pack_frag(p0[2 * kk] * b0 * a, p0[2 * kk + 1] * b1 * a);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag_vimg(vimg, kk * 32, dt, lane), pf, o[dt]);
+            }
+            if (q < N) {
+                bf16_t* dst = p.o + ((long long)b * N + q) * (p.H * DH) + h * DH + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) store_bf16x4(dst + dt * 16, o[dt]);
+            }
+        }
+        if (!L::TWO) {                             // one image pair: the next head's images replace this head's (grid = heads: no next head)
+            __syncthreads();
         }
     }
 }
@@ -242,29 +304,6 @@ struct SkBwdLds {
     static constexpr int IMAGES = THREE ? 3 : 2;
     static constexpr int BYTES = IMAGES * NP * 128 + VEC + CH * RS;
 };
-
-// LDS-DMA of one [N x 64] bf16 head slice (row stride ld elements) into a row image with the img_off swizzle (applied to the
-// SOURCE chunk: the LDS side of a DMA instruction is lane-linear); rows >= N read as zero.  Asynchronous: vmcnt.
-template <int NP, int NWAVES>
-__device__ __forceinline__ void dma_image(char* img, const bf16_t* src, long long ld, int N, int wave_u, int lane) {
-    // the head's base address is uniform but comes out of an integer division (VALU): pin it to scalar registers, the
-    // descriptor of the DMA must live in SGPRs
-    const unsigned long long a = reinterpret_cast<unsigned long long>(src);
-    const unsigned a_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));      // the builtin returns int: go through
-    const unsigned a_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);              // unsigned before widening
-    const unsigned long long au = ((unsigned long long)a_hi << 32) | (unsigned long long)a_lo;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const bf16_t*>(au), 0x7fffffffull);
-    constexpr int NI = NP / 8;
-#pragma unroll
-    for (int i = 0; i < (NI + NWAVES - 1) / NWAVES; ++i) {
-        const int j = wave_u + NWAVES * i;
-        if (j < NI) {                                          // wave-uniform
-            const int r = 8 * j + (lane >> 3), pos = lane & 7;
-            const int c = pos ^ ((r >> 1) & 7);
-            dma16(rs, img + j * 1024, r < N ? (unsigned)(r * ld * 2 + c * 16) : NRV_OOB);
-        }
-    }
-}
 
 template <int NP, int TPW>
 __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_kernel(const SinkParams p) {
@@ -729,9 +768,9 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
             __syncthreads();
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // the next head's Q fragments / LSE (its K image: waited for above, published by the barriers) --
+    asm volatile("" ::: "memory");             // before the dK stores, whose latency then overlaps the next head's start
     store_key_rows(dk, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // the next head's Q fragments / LSE (and its K image: waited for above, published by the barriers)
-    asm volatile("" ::: "memory");
     SK_STAMP();           // 10: dK phase
     }
 #undef SK_STAMP
@@ -749,11 +788,13 @@ int sk_cus() {
 
 template <int NP>
 int launch_sk_fwd(const SinkParams& p, hipStream_t s) {
-    constexpr int lds = 2 * NP * 128 + (1 + SK_WAVES) * NP * 4;
+    constexpr int lds = SkFwdLds<NP>::BYTES;
     static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_fwd_kernel<NP>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != 0) return attr;
-    hipLaunchKernelGGL((sinkhorn_fwd_kernel<NP>), dim3(p.B * p.H), dim3(SK_THREADS), lds, s, p);
+    const int heads = p.B * p.H;
+    const int grid = SkFwdLds<NP>::TWO && heads > sk_cus() ? sk_cus() : heads;
+    hipLaunchKernelGGL((sinkhorn_fwd_kernel<NP>), dim3(grid), dim3(SK_THREADS), lds, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }
