@@ -608,6 +608,33 @@ def test_sinkhorn_attention_fwd_bwd(dev, B, N, H):
     assert rel < 3e-2 and cos > 0.999, (rel, cos)
 
 
+@pytest.mark.parametrize("B,N,H", [(45, 197, 6), (90, 49, 3), (23, 256, 12)])
+def test_sinkhorn_attention_persistent_walk_over_many_heads(dev, B, N, H):
+    """The fused Sinkhorn kernels are persistent (one workgroup per CU walks the heads, the next head's operands arrive during
+    the current one): more heads than CUs with a remainder (270 / 276 heads on 256 CUs), every head against the fp32 definition,
+    and the same bits from a second launch (no dependence on which workgroup ran which head when)."""
+    k = _k()
+    dh = 64
+    scale = dh ** -0.5
+    qkv = rnd((B * N, 3 * H * dh), dev, 163, 1.0)
+    dout = rnd((B * N, H * dh), dev, 164, 1.0)
+    out, lse, scal = k.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
+    dqkv = k.attn_sinkhorn_bwd(qkv, dout, lse, scal, B, N, H, dh, scale)
+    out2, lse2, scal2 = k.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
+    dqkv2 = k.attn_sinkhorn_bwd(qkv, dout, lse2, scal2, B, N, H, dh, scale)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(scal, scal2) and torch.equal(dqkv, dqkv2)
+    qr = qkv.float().requires_grad_(True)
+    ref_o, _ = sinkhorn_ref(qr, B, N, H, dh, scale)
+    ref_o.backward(dout.float())
+    # per head: a wrong operand of ONE head (a prefetch into the wrong slot) must not hide in a global norm
+    o_err = (out.float() - ref_o.detach()).reshape(B, N, H, dh).abs().amax(dim=(1, 3)) / ref_o.detach().abs().max()
+    assert o_err.max().item() < 2 ** -6, o_err.max().item()
+    g = dqkv.float().reshape(B, N, 3, H, dh)
+    r = qr.grad.reshape(B, N, 3, H, dh)
+    rel = (g - r).pow(2).sum(dim=(1, 2, 4)).sqrt() / r.pow(2).sum(dim=(1, 2, 4)).sqrt()
+    assert rel.max().item() < 3e-2, rel.max().item()
+
+
 # robust=True beyond the fused kernels' shapes (N > 256 or dh != 64): composed from nrv_bgemm + nrv_sinkhorn_fwd / bwd on the
 # materialised scores -- vit_h_14 (257 tokens, 16 heads x 80), ViT-B/16 at 384 px (577 tokens), SimpleViT(dim_head = 32 / 96 / 128)
 @pytest.mark.parametrize("B,N,H,dh", [(2, 257, 4, 80), (1, 577, 3, 64), (2, 400, 2, 32), (2, 100, 3, 96), (1, 300, 2, 128), (3, 17, 2, 32)])
