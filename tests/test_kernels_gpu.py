@@ -869,7 +869,8 @@ def test_sinkhorn_module_on_scores_matches_reference_fixture(dev, golden_dir):
 
 
 @pytest.mark.parametrize("shape,iters", [((2, 3, 7, 7), 3), ((4, 197, 197), 3), ((1, 2, 300, 300), 3), ((3, 50, 81), 3),
-                                         ((2, 64, 64), 0), ((2, 33, 65), 5), ((1, 1, 1), 3)])
+                                         ((2, 64, 64), 0), ((2, 33, 65), 5), ((1, 1, 1), 3),
+                                         ((2, 577, 577), 3), ((1, 40, 700), 2), ((1, 100, 1500), 1), ((1, 24, 2500), 1), ((1, 300, 20), 3)])
 def test_sinkhorn_module_forward_backward(dev, shape, iters):
     from noise_robust_vit_amd import SinkhornAttention
     S = rnd(shape, dev, 170, 1.5, torch.float32).requires_grad_(True)
