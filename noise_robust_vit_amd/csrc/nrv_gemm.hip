@@ -54,7 +54,7 @@ using Cfg256 = TileCfg<2, 4, 8, 4>;
 using Cfg320 = TileCfg<2, 4, 10, 4>;
 // 128-column tiles (4 x 2 waves) for N that is a multiple of 128 but wastes a quarter or more of a 256-column grid
 // (N = 384: ViT-S): the same 64 KiB of operands per K-tile as Cfg256 for 3/4 of its MFMA work, but no padding columns
-using Cfg384n = TileCfg<4, 2, 6, 4>;     // 384 x 128  (256 x 128 measured slower on every shape)
+using Cfg384n = TileCfg<4, 2, 6, 4>;     // 384 x 128  (256 x 128 measured slower on every shape); phased persistent kernel since round 4
 constexpr int EPI_ROW_F32 = 68;             // 64 floats + 4 pad  (272 B rows: conflict-free b128 writes)
 constexpr int EPI_PATCH_BYTES = 16 * EPI_ROW_F32 * 4;   // 4352 B per wave
 
@@ -567,7 +567,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt_kernel(const GemmNTPara
 //         phase 0: read B0, A0 | quadrant (A0, B0)      phase 2: read A1 | quadrant (A1, B1)
 //         phase 1: read B1     | quadrant (A0, B1)      phase 3: --      | quadrant (A1, B0)   (B0 stays in registers)
 //     each phase = [fragment reads + ONE half-tile of LDS-DMA + counted vmcnt] s_barrier [MFMAs] s_barrier.
-//   * Waves 4-7 (wave row 1; the SIMD partners of waves 0-3) run ONE barrier behind waves 0-3: on every SIMD one wave is in
+//   * Waves 4-7 (wave row 1 of a 2 x 4 layout, wave rows 2-3 of the 4 x 2 layout of the 384 x 128 tile; the SIMD partners of waves 0-3)
+//     run ONE barrier behind waves 0-3: on every SIMD one wave is in
 //     its MFMA section while the other reads fragments and issues DMA.
 //   * Half-tile op n = 4 t + {A0, B0, B1, A1} of K-step t is issued in global phase n - 6 (a half is re-staged >= 2 phases
 //     after its last fragment read in either wave group) and first read in phase >= n - 1: five phases (2.5 K-step
@@ -616,7 +617,7 @@ struct Nt8Tile {                     // what the staging ops and the epilogue of
 //     passes, falls back to the plain count and waits for its stores): the K loop does not wait for the store drain.
 template <typename C, int EPI, bool OUT_F32, bool AUX_F32>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTParams p) {
-    static_assert(C::WM == 2 && C::WN == 4 && C::NI == 4 && C::MI % 2 == 0, "2 x 4 waves, 64-column wave blocks");
+    static_assert(((C::WM == 2 && C::WN == 4) || (C::WM == 4 && C::WN == 2)) && C::NI == 4 && C::MI % 2 == 0, "2 x 4 or 4 x 2 waves, 64-column wave blocks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MH = C::MI / 2;                                   // row tiles per wave and half
     constexpr int AH = C::TBM / 2 * 128, BH = C::TBN / 2 * 128;     // bytes of a half-tile image (128-byte rows)
@@ -635,7 +636,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / C::WN, wc = wave % C::WN;                 // the wave's block of the tile
+    const int grp = wave >> 2, wq = wave & 3;                       // wave group (waves w and w + 4 share a SIMD) and index within it
     NRV_TILE_STAMP_VARS(wave);       // hooks: empty in the product (csrc/nrv_dev.hpp)
     NRV_WACC_VARS;
     NRV_TILE_STAMP();                // [0] start
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int q = i * 8 + wave;
-        if (A_UNEVEN && i == NA - 1) q = (NA - 1) * 8 + (wave & 3);          // issued by waves 0-3 (h = 0) / 4-7 (h = 1) only
+        if (A_UNEVEN && i == NA - 1) q = (NA - 1) * 8 + wq;                  // issued by waves 0-3 (h = 0) / 4-7 (h = 1) only
         const int rl = q * 8 + (lane >> 3);
         const int r = (C::MI * 16) * (rl / (8 * C::MI)) + rl % (8 * C::MI);
         const int c = (lane & 7) ^ ((rl >> 1) & 7);
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (A_UNEVEN && i == NA - 1) {
-                    if (wr == h) dma16s_at(r, base + ((NA - 1) * 8 + (wave & 3)) * 1024, st_a[i], so);
+                    if (grp == h) dma16s_at(r, base + ((NA - 1) * 8 + wq) * 1024, st_a[i], so);
                 } else {
                     dma16s_at(r, base + (i * 8 + wave) * 1024, st_a[i], so);
                 }
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
     stage(I0{}, cur, 0, 0); stage(I1{}, cur, 0, 0); stage(I2{}, cur, 0, 0); stage(I3{}, cur, 0, 0); stage(I0{}, cur, 1, 1); stage(I1{}, cur, 1, 1);
     wait_vm<W4>();
     __builtin_amdgcn_s_barrier();
-    if (NRV_TUNE_STAGGER(wr == 1)) __builtin_amdgcn_s_barrier();                      // stagger: waves 4-7 one barrier behind
+    if (NRV_TUNE_STAGGER(grp == 1)) __builtin_amdgcn_s_barrier();                     // stagger: waves 4-7 one barrier behind
     NRV_WACC_MARK();
 
     bool count_stores = false;       // the previous epilogue of this wave issued exactly E_OPS counted instructions
@@ -889,13 +891,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         // re-align the wave groups for the epilogue (staggered, waves 4-7 would sit in their last barrier through the epilogue
         // of waves 0-3 and run theirs afterwards: the two epilogues one after the other, measured +2 .. 7 us per tile)
         NRV_TILE_STAMP();            // [2 + 4 i] K loop done
-        if (NRV_TUNE_STAGGER(wr == 0)) __builtin_amdgcn_s_barrier();
+        if (NRV_TUNE_STAGGER(grp == 0)) __builtin_amdgcn_s_barrier();
         NRV_TILE_STAMP();            // [3 + 4 i] wave groups re-aligned
         // epilogue patches: waves 0-3 behind the stage buffers, waves 4-7 in the A1 half of the stage the last K-step used
         // (after next_stage() that is the buffer the read addresses do NOT point at)
         {
             const unsigned ybase = dstg > 0 ? (unsigned)STG : 0u;
-            char* patch = smem + ((PATCH_BEHIND || wr == 0) ? 2 * STG + wave * 4096 : (int)ybase + AH + wc * 4096);
+            char* patch = smem + ((PATCH_BEHIND || grp == 0) ? 2 * STG + wave * 4096 : (int)ybase + AH + wq * 4096);
             const int row_base = cur.m0 + wr * (C::MI * 16), col_base = cur.n0 + wc * 64;
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));        // opaque per tile: the epilogue's per-lane offsets are recomputed here, not kept in registers through the K loops
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
         }
         NRV_TILE_STAMP();            // [4 + 4 i] epilogue issued
         if (!has_next) break;
-        if (NRV_TUNE_STAGGER(wr == 1)) __builtin_amdgcn_s_barrier();                  // stagger again: waves 4-7 one barrier behind
+        if (NRV_TUNE_STAGGER(grp == 1)) __builtin_amdgcn_s_barrier();                 // stagger again: waves 4-7 one barrier behind
         kb = (kb + nk) & 1;
         cur = nxt;
         t = tnext;
@@ -1695,13 +1697,16 @@ int nt_tile_choice(int64_t M, int64_t N, int64_t K, bool allow_384n) {
 
 template <int EPI, bool OUT_F32, bool AUX_F32>
 int launch_nt(const GemmNTParams& p, hipStream_t s) {
-    // the 384 x 128 tile keeps the two-stage loop: with the fp32 residual epilogue and a long K the phased 256 x 256 loop wins
-    // although it computes the padding columns (profiles/r03_nt_tile_sweep.txt: [50432 x 384 x 1536] 94.8 vs 111.1 us)
+    // with the fp32 residual epilogue and a long K the 256 x 256 tile wins although it computes the padding columns
+    // (profiles/r04_nt8_384x128_tile_phased.txt: [50432 x 384 x 1536] 91.5 vs 93.6 us with both tiles on the phased kernel)
     const bool allow_384n = !(EPI == NRV_EPI_BIAS_RESIDUAL && p.K >= 1024);
     const int tc = NRV_TUNE_NT_TILE(nt_tile_choice(p.e.M, p.e.N, p.K, allow_384n));      // identity in the product (csrc/nrv_dev.hpp)
     if (EPI == NRV_EPI_BIAS_RESIDUAL && (p.e.out_group > 0 || p.e.aux_row_mod > 0))       // row scatter / operand-row broadcast
         return launch_nt_cfg<Cfg256, NRV_EPI_BIAS_RESIDUAL, OUT_F32, AUX_F32, true>(p, s);    // one launch per step: 256-row tiles only
-    if (tc == 1384) return launch_nt_cfg<Cfg384n, EPI, OUT_F32, AUX_F32, false>(p, s);
+    if (tc == 1384) {
+        if ((p.K & (BK - 1)) == 0 && p.K >= 3 * BK) return launch_nt8_cfg<Cfg384n, EPI, OUT_F32, AUX_F32>(p, s);
+        return launch_nt_cfg<Cfg384n, EPI, OUT_F32, AUX_F32, false>(p, s);
+    }
     // phased main loop: whole K-steps only, and at least three of them (its prologue issues 1.5 K-steps, its tail peels two)
     if ((p.K & (BK - 1)) == 0 && p.K >= 3 * BK) {
         if (tc == 320) return launch_nt8_cfg<Cfg320, EPI, OUT_F32, AUX_F32>(p, s);
