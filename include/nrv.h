@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 11
+#define NRV_ABI_VERSION 12
 
 /* dtype codes */
 #define NRV_F32 0
@@ -251,6 +251,14 @@ int nrv_cast_transpose_batched(const nrv_cast_job* jobs_dev, int njobs, int64_t 
 
 /* Elementwise cast fp32 -> bf16 (n % 8 == 0 not required). */
 int nrv_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+
+/* Dropout with p > 0 (training; reference: nn.Dropout at vit.py:100-101 (MLPBlock), :112,125 (EncoderBlock), :154,175 (Encoder)).
+ * The keep mask is the caller's data: one byte per element (0 = dropped), n % 8 == 0, 8-byte aligned; scale = 1 / (1 - p).
+ *   nrv_dropout_add_f32:  out = x + y * (keep ? scale : 0)   fp32 residual stream x, fp32 branch output y (out may alias x or y)
+ *   nrv_mask_mul_bf16:    out = a * (keep ? scale : 0)       bf16 (out may alias a): GELU output, gelu' stream, branch gradient
+ * attention_dropout (inside the attention kernels) is not implemented: the modules raise for it. */
+int nrv_dropout_add_f32(const float* x, const float* y, const unsigned char* keep, float* out, float scale, int64_t n, void* stream);
+int nrv_mask_mul_bf16(const void* a_bf16, const unsigned char* keep, void* out_bf16, float scale, int64_t n, void* stream);
 
 /* Row gather / scatter-add of the residual stream (MAE token selection, mae.py:75-76 and its backward):
  *   fwd: out[r, :] = src[index[r], :]   (rows_out rows, dim % 4 == 0, fp32; src has rows_src rows)

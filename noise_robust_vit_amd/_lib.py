@@ -18,7 +18,7 @@ LIB_PATH = _DEFAULT_LIB       # no environment override: what runs is the in-tre
 NRV_F32, NRV_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 ATTN_QKV_BLOCKED, ATTN_OUT_BLOCKED = 1, 2      # include/nrv.h: NRV_ATTN_*_BLOCKED
 
 
@@ -62,6 +62,8 @@ SIGNATURES = {
     "nrv_cast_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "nrv_cast_transpose_batched": (c_int, [c_void_p, c_int, c_int64, c_void_p]),
     "nrv_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nrv_dropout_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "nrv_mask_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "nrv_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "nrv_scatter_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "nrv_sumsq_workspace": (c_size_t, [c_int64]),

@@ -146,6 +146,43 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
     }
 }
 
+// Dropout (p > 0 in training: vit.py:100-101,112,125,154,175).  The keep mask is DATA (one byte per element, drawn by the caller's
+// generator and saved for the backward); these two kernels apply it.  scale = 1 / (1 - p) is a float argument: a bf16 mask of
+// 1 / (1 - p) would round the scale itself to 8 bits.
+//   dropout_add:  out = x + y * (keep ? scale : 0)      the residual stream takes a dropped branch output (fp32)
+//   mask_mul:     out = a * (keep ? scale : 0)           bf16 tensors: the GELU output, the gelu' stream, the branch's incoming gradient
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const unsigned char* __restrict__ keep, float* __restrict__ out, float scale, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x2_t k = *reinterpret_cast<const u32x2_t*>(keep + i * 8);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(x + i * 8 + 4 * h);
+            const f32x4_t yv = *reinterpret_cast<const f32x4_t*>(y + i * 8 + 4 * h);
+            f32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = xv[e] + (((k[h] >> (8 * e)) & 0xffu) ? yv[e] * scale : 0.f);
+            *reinterpret_cast<f32x4_t*>(out + i * 8 + 4 * h) = o;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void mask_mul_kernel(const bf16_t* __restrict__ a, const unsigned char* __restrict__ keep,
+                                                       bf16_t* __restrict__ out, float scale, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x2_t k = *reinterpret_cast<const u32x2_t*>(keep + i * 8);
+        const u32x4_t av = *reinterpret_cast<const u32x4_t*>(a + i * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned kb = k[w >> 1] >> (16 * (w & 1));
+            const float lo = (kb & 0xffu) ? bf16lo_to_f32(av[w]) * scale : 0.f;
+            const float hi = (kb & 0xff00u) ? bf16hi_to_f32(av[w]) * scale : 0.f;
+            o[w] = pack_bf16x2(lo, hi);
+        }
+        *reinterpret_cast<u32x4_t*>(out + i * 8) = o;
+    }
+}
+
 // rows of the fp32 residual stream: gather out[r] = src[index[r]]; scatter dsrc[index[r]] = dout[r].  The indices are device data
 // (a permutation computed by the caller's kernels): an index outside [0, rows_src) can never become an address -- the gather
 // writes a zero row for it, the scatter drops the row (ABI 11; the host cannot validate device data without a sync).
@@ -273,6 +310,27 @@ extern "C" int nrv_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* 
     if (!nrv_aligned16(x) || !nrv_aligned16(y_bf16)) return NRV_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, x, static_cast<bf16_t*>(y_bf16), (long long)n);
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nrv_dropout_add_f32(const float* x, const float* y, const unsigned char* keep, float* out, float scale, int64_t n, void* stream) {
+    if (!x || !y || !keep || !out) return NRV_ERR_NULL;
+    if (n <= 0 || (n & 7)) return NRV_ERR_SHAPE;
+    if (!nrv_aligned16(x) || !nrv_aligned16(y) || !nrv_aligned16(out) || (reinterpret_cast<uintptr_t>(keep) & 7u)) return NRV_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, s, x, y, keep, out, scale, (long long)(n >> 3));
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nrv_mask_mul_bf16(const void* a_bf16, const unsigned char* keep, void* out_bf16, float scale, int64_t n, void* stream) {
+    if (!a_bf16 || !keep || !out_bf16) return NRV_ERR_NULL;
+    if (n <= 0 || (n & 7)) return NRV_ERR_SHAPE;
+    if (!nrv_aligned16(a_bf16) || !nrv_aligned16(out_bf16) || (reinterpret_cast<uintptr_t>(keep) & 7u)) return NRV_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mask_mul_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, s, static_cast<const bf16_t*>(a_bf16), keep,
+                       static_cast<bf16_t*>(out_bf16), scale, (long long)(n >> 3));
     NRV_CHECK_LAUNCH();
     return 0;
 }

@@ -129,6 +129,11 @@ class BlockMeta:
     robust: bool = False
     # optional gradient sink (data-parallel runtime): grad_out(param) -> (tensor, beta) or None
     sink: Optional[object] = None
+    # residual / MLP dropout of the block stack (vit.py:100-101,112,125): probability for the NEXT forward (the modules set it
+    # from their own p and training flag) and an optional source of keep masks, site -> uint8 tensor (tests inject the masks the
+    # oracle uses; default: torch's device generator).  Sites of layer i: 3 i (attention branch), 3 i + 1 (GELU output), 3 i + 2 (MLP branch).
+    dropout: float = 0.0
+    mask_source: Optional[object] = None
 
 
 def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
@@ -311,7 +316,17 @@ def _record(qkv: Tensor, aux, B: int, N: int, H: int, dh: int, scale: float, rob
 # ----------------------------------------------------------------------------------------------
 # attention half
 # ----------------------------------------------------------------------------------------------
-def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool):
+def draw_keep(meta: BlockMeta, site: int, shape, device) -> Tensor:
+    """uint8 keep mask of one dropout site (1 = kept)."""
+    if meta.mask_source is not None:
+        m = meta.mask_source(site, tuple(shape))
+        if m.dtype != torch.uint8 or tuple(m.shape) != tuple(shape):
+            raise NrvError(f"mask_source({site}): expected a uint8 mask of shape {tuple(shape)}")
+        return m.to(device).contiguous()
+    return (torch.rand(shape, device=device) >= meta.dropout).to(torch.uint8)
+
+
+def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, drop=None):
     """x fp32 [B*N, D] -> (y fp32 [B*N, D], saved).  `ln_w is None`: no LayerNorm in front of the projection (the bare
     `MultiheadAttention.forward` of the reference's forked module, utils.py:741-751)."""
     H, dh = meta.heads, meta.dim_head
@@ -331,22 +346,31 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
         o, aux = K.attn_fwd(qkv, B, N, H, dh, scale)
     if _RECORDING is not None:
         _record(qkv, aux, B, N, H, dh, scale, meta.robust)
-    if residual:
+    keep = None
+    if residual and drop is not None:
+        # dropout on the branch output (vit.py:125): the bias epilogue writes the branch, one pass adds what is kept to the stream
+        scale, site = drop
+        keep = draw_keep(meta, site, x.shape, x.device)
+        yb = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS if bo is not None else EPI_NONE, bias=bo)
+        y = K.dropout_add(x, yb, keep, scale, out=yb)
+    elif residual:
         y = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bo, aux=x)
     else:
         y = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS if bo is not None else EPI_NONE, bias=bo)
-    return y, (x, xn, mean, rstd, qkv, o, aux)
+    return y, (x, xn, mean, rstd, qkv, o, aux, keep)
 
 
 def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int, N: int, meta: BlockMeta,
-                  ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, want_bf16: bool, want_f32: bool = True):
+                  ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, want_bf16: bool, want_f32: bool = True, drop_scale: float = 1.0):
     """Returns (dx32|None, dx16|None, [d ln_w, d ln_b, d wqkv, d bqkv, d wo, d bo]).
 
     The incoming gradient is given as fp32 (`dy32`), bf16 (`dy16`) or both; the residual add uses fp32 when present."""
-    x, xn, mean, rstd, qkv, o, aux = saved
+    x, xn, mean, rstd, qkv, o, aux, keep = saved
     H, dh = meta.heads, meta.dim_head
     if dy16 is None:
         dy16 = K.cast_bf16(dy32)
+    if keep is not None:                 # the branch sees the dropped gradient; the residual path (dres below) the whole one
+        dy16 = K.mask_mul(dy16, keep, drop_scale)
     _, wo_t = WEIGHTS.get(wo, True)
     _, wqkv_t = WEIGHTS.get(wqkv, True)
     # out-proj:  y = o Wo^T (+bo) (+x)
@@ -366,6 +390,8 @@ def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int,
     dxn = K.gemm_nt(dqkv, wqkv_t, out_dtype=torch.bfloat16)
     tg, bg = _grad_target(meta, ln_w)
     tb, _ = _grad_target(meta, ln_b)
+    if residual and keep is not None and dy32 is None:
+        raise NrvError("dropout needs the fp32 residual gradient")
     dres = (dy32 if dy32 is not None else dy16) if residual else None
     dx32, dx16, dg, db = K.layernorm_bwd(dxn, x, ln_w, mean, rstd, dres=dres,
                                          want_f32=want_f32, want_bf16=want_bf16, dgamma=tg, dbeta=tb, accumulate=bg != 0.0)
@@ -375,7 +401,7 @@ def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int,
 # ----------------------------------------------------------------------------------------------
 # MLP half
 # ----------------------------------------------------------------------------------------------
-def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residual: bool, save: bool = True):
+def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residual: bool, save: bool = True, drop=None):
     """`save=False` (no gradient will be asked for): the fc1 epilogue skips the gelu'(u) output -- a 310 MB store stream per
     layer on ViT-B/16 at batch 256."""
     xn, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, meta.eps)
@@ -384,18 +410,34 @@ def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residua
     T = x.shape[0]
     u = torch.empty(T, w1.shape[0], dtype=torch.bfloat16, device=x.device) if save else None     # receives gelu'(pre-activation)
     h = K.gemm_nt(xn, w1_b, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=b1, aux_out=u)
-    if residual:
+    keep2 = None
+    if residual and drop is not None:
+        # Dropout behind the GELU (vit.py:100) and behind the second Linear (vit.py:101).  The first mask is applied to the saved
+        # activation AND to the gelu' stream, so the backward (dW2 = dY^T h, dU = dY W2 o gelu') needs no mask of its own.
+        scale, site = drop
+        keep1 = draw_keep(meta, site, h.shape, x.device)
+        K.mask_mul(h, keep1, scale, out=h)
+        if u is not None:
+            K.mask_mul(u, keep1, scale, out=u)
+        keep2 = draw_keep(meta, site + 1, x.shape, x.device)
+        yb = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS if b2 is not None else EPI_NONE, bias=b2)
+        y = K.dropout_add(x, yb, keep2, scale, out=yb)
+    elif residual:
         y = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=b2, aux=x)
     else:
         y = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS if b2 is not None else EPI_NONE, bias=b2)
-    return y, (x, xn, mean, rstd, u, h)
+    return y, (x, xn, mean, rstd, u, h, keep2)
 
 
 def mlp_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, meta: BlockMeta,
-                 ln_w, ln_b, w1, b1, w2, b2, residual: bool, want_bf16: bool, want_f32: bool = True):
-    x, xn, mean, rstd, u, h = saved
+                 ln_w, ln_b, w1, b1, w2, b2, residual: bool, want_bf16: bool, want_f32: bool = True, drop_scale: float = 1.0):
+    x, xn, mean, rstd, u, h, keep2 = saved
     if dy16 is None:
         dy16 = K.cast_bf16(dy32)
+    if keep2 is not None:
+        if dy32 is None:
+            raise NrvError("dropout needs the fp32 residual gradient")
+        dy16 = K.mask_mul(dy16, keep2, drop_scale)
     _, w2_t = WEIGHTS.get(w2, True)
     _, w1_t = WEIGHTS.get(w1, True)
     dw2, db2 = _dw_db(meta, dy16, h, w2, b2)
@@ -444,12 +486,17 @@ class EncoderStackFn(torch.autograd.Function):
         saved = []
         cur = x2
         train = any(ctx.needs_input_grad)            # inference (torch.no_grad / frozen model): keep nothing for a backward
+        pdrop = float(meta.dropout)
+        if not 0.0 <= pdrop < 1.0:
+            raise NrvError(f"dropout probability {pdrop} outside [0, 1)")
+        scale = 1.0 / (1.0 - pdrop)
         for i in range(depth):
             p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            cur, sa = attn_half_fwd(cur, B, N, meta, *p[0:6], residual=True)
-            cur, sm = mlp_half_fwd(cur, meta, *p[6:12], residual=True, save=train)
+            cur, sa = attn_half_fwd(cur, B, N, meta, *p[0:6], residual=True, drop=(scale, 3 * i) if pdrop > 0.0 else None)
+            cur, sm = mlp_half_fwd(cur, meta, *p[6:12], residual=True, save=train, drop=(scale, 3 * i + 1) if pdrop > 0.0 else None)
             saved.append((sa, sm) if train else None)
         ctx.meta, ctx.params, ctx.saved_blocks, ctx.shape = meta, params, saved, (B, N, D)
+        ctx.drop_scale = scale
         return cur.reshape(B, N, D)
 
     @staticmethod
@@ -466,8 +513,8 @@ class EncoderStackFn(torch.autograd.Function):
         for i in reversed(range(depth)):
             p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             sa, sm = saved[i]
-            d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True)
-            d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0)
+            d32, d16, gm = mlp_half_bwd(d32, d16, sm, meta, *p[6:12], residual=True, want_bf16=True, drop_scale=ctx.drop_scale)
+            d32, d16, ga = attn_half_bwd(d32, d16, sa, B, N, meta, *p[0:6], residual=True, want_bf16=i > 0, drop_scale=ctx.drop_scale)
             grads[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = ga + gm
             # the previous layer's grouped weight-gradient launch (side stream: it ran beside this layer's dX chain) is joined
             # and its parameters declared final; then this layer's four gradients go out as one launch

@@ -508,6 +508,42 @@ def cast_bf16(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return y
 
 
+def _keep_mask(keep: Tensor, like: Tensor, what: str) -> None:
+    _dev(keep, "keep")
+    if keep.dtype != torch.uint8 or not keep.is_contiguous() or keep.numel() != like.numel():
+        raise NrvError(f"{what}: keep must be a contiguous uint8 mask with one byte per element")
+    if like.numel() % 8:
+        raise NrvError(f"{what}: the element count must be a multiple of 8")
+
+
+def dropout_add(x: Tensor, y: Tensor, keep: Tensor, scale: float, out: Optional[Tensor] = None) -> Tensor:
+    """out = x + y * (keep ? scale : 0): the fp32 residual stream takes a dropped branch output (include/nrv.h nrv_dropout_add_f32)."""
+    _f32(x, "x"); _f32(y, "y")
+    if not (x.is_contiguous() and y.is_contiguous()) or x.shape != y.shape:
+        raise NrvError("dropout_add: x and y must be contiguous fp32 tensors of one shape")
+    _keep_mask(keep, x, "dropout_add")
+    o = torch.empty_like(x) if out is None else out
+    lib = _lib.load()
+    _run("dropout", 0.0, x.numel() * 13,
+         lambda: lib.nrv_dropout_add_f32(x.data_ptr(), y.data_ptr(), keep.data_ptr(), o.data_ptr(), float(scale), x.numel(), _stream()),
+         "nrv_dropout_add_f32")
+    return o
+
+
+def mask_mul(a: Tensor, keep: Tensor, scale: float, out: Optional[Tensor] = None) -> Tensor:
+    """out = a * (keep ? scale : 0) on bf16 tensors (include/nrv.h nrv_mask_mul_bf16); `out=a` works in place."""
+    _bf16(a, "a")
+    if not a.is_contiguous():
+        raise NrvError("mask_mul: a must be contiguous")
+    _keep_mask(keep, a, "mask_mul")
+    o = torch.empty_like(a) if out is None else out
+    lib = _lib.load()
+    _run("dropout", 0.0, a.numel() * 5,
+         lambda: lib.nrv_mask_mul_bf16(a.data_ptr(), keep.data_ptr(), o.data_ptr(), float(scale), a.numel(), _stream()),
+         "nrv_mask_mul_bf16")
+    return o
+
+
 def gather_rows(src: Tensor, index: Tensor) -> Tensor:
     """out[r] = src[index[r]]; src fp32 [R, dim], index int64 [rows_out]."""
     _f32(src, "src"); _dev(index, "index")

@@ -30,7 +30,17 @@ __all__ = ["VisionTransformer", "Encoder", "EncoderBlock", "MLPBlock", "Multihea
 
 def _no_dropout(p: float, what: str) -> None:
     if p != 0.0:
-        raise NotImplementedError(f"{what}={p}: the fused HIP path implements dropout p=0 only (reference default)")
+        raise NotImplementedError(f"{what}={p}: dropout inside the attention kernels is not implemented (reference default 0); "
+                                  "`dropout` (MLP / residual branches, encoder input) is")
+
+
+def _input_dropout(x: torch.Tensor, meta: BlockMeta, p: float) -> torch.Tensor:
+    """Encoder-level dropout on the embedded tokens (vit.py:154,175): once per step, plain tensor ops.  Site -1 of the mask source."""
+    if meta.mask_source is not None:
+        keep = meta.mask_source(-1, tuple(x.shape)).to(x.device)
+    else:
+        keep = torch.rand(x.shape, device=x.device) >= p
+    return x * (keep.to(x.dtype) * (1.0 / (1.0 - p)))
 
 
 class MultiheadAttention(nn.Module):
@@ -140,12 +150,12 @@ class EncoderBlock(nn.Module):
 
     def check_dropout(self):
         if self.training:
-            _no_dropout(self.dropout.p, "dropout")
             _no_dropout(self.self_attention.dropout, "attention_dropout")
 
     def forward(self, input: torch.Tensor):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         self.check_dropout()
+        self._meta.dropout = self.dropout.p if self.training else 0.0          # vit.py:100-101,125
         return EncoderStackFn.apply(input, self._meta, *self.layer_params())
 
 
@@ -173,12 +183,14 @@ class Encoder(nn.Module):
         for blk in self.layers:
             blk.check_dropout()
             flat += blk.layer_params()
+        p = self.dropout.p if self.training else 0.0
+        self._meta.dropout = p                                      # the blocks' MLP / branch dropout (vit.py:100-101,125): same p (vit.py:161)
+        if p > 0.0:
+            x = _input_dropout(x, self._meta, p)                    # vit.py:175
         return EncoderStackFn.apply(x, self._meta, *flat)
 
     def forward(self, input: torch.Tensor):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
-        if self.training:
-            _no_dropout(self.dropout.p, "dropout")
         x = self.run_stack(input + self.pos_embedding)
         return torch.nn.functional.layer_norm(x, (x.shape[-1],), self.ln.weight, self.ln.bias, self.ln.eps)
 
@@ -244,8 +256,6 @@ class VisionTransformer(nn.Module):
         n, c, h, w = x.shape
         torch._assert(h == self.image_size, f"Wrong image height! Expected {self.image_size} but got {h}!")
         torch._assert(w == self.image_size, f"Wrong image width! Expected {self.image_size} but got {w}!")
-        if self.training:
-            _no_dropout(self.encoder.dropout.p, "dropout")
         # conv_proj + class token + pos_embedding in one GEMM epilogue (vit.py:323-342, Encoder :174)
         tokens = PatchEmbedFn.apply(x, self.conv_proj.weight, self.conv_proj.bias, self.encoder.pos_embedding,
                                     self.class_token, self.patch_size, PATCH_CP1P2, self._sink)

@@ -70,28 +70,45 @@ def mha_self_attention(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out
     return o @ Q(out_w, "w").t() + out_b
 
 
+def _drop(t: Tensor, drop, site: int) -> Tensor:
+    """nn.Dropout in training mode with a GIVEN keep mask: t * keep / (1 - p) (vit.py:100-101,125,175).  `drop` = (p, keep) with
+    keep(site, shape) -> mask tensor (nonzero = kept); None = no dropout.  The random stream of torch's own nn.Dropout is not part
+    of the contract: parity is defined for injected masks."""
+    if drop is None:
+        return t
+    p, keep = drop
+    return t * (keep(site, tuple(t.shape)).to(t.dtype) * (1.0 / (1.0 - p)))
+
+
 def encoder_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, robust: bool, Q: _Q,
-                  eps: float = 1e-6, capture: Optional[dict] = None, tag: str = "") -> Tensor:
-    """EncoderBlock.forward, vit.py:118-130 (dropout p=0).  `capture[tag + ".attn_out"]` receives the residual stream
-    after the attention half (vit.py:126), for the per-half localisation in tests/test_model_gpu.py."""
+                  eps: float = 1e-6, capture: Optional[dict] = None, tag: str = "", drop=None, layer: int = 0) -> Tensor:
+    """EncoderBlock.forward, vit.py:118-130.  `capture[tag + ".attn_out"]` receives the residual stream
+    after the attention half (vit.py:126), for the per-half localisation in tests/test_model_gpu.py.  Dropout sites of layer i:
+    3 i the attention branch (vit.py:125), 3 i + 1 behind the GELU (vit.py:100), 3 i + 2 behind the second Linear (vit.py:101);
+    the masks are over the flattened [batch * tokens, features] matrices."""
     a = Q(layer_norm(x, sd[pfx + "ln_1.weight"], sd[pfx + "ln_1.bias"], eps), "xn")
     a = mha_self_attention(a, sd[pfx + "self_attention.in_proj_weight"], sd[pfx + "self_attention.in_proj_bias"],
                            sd[pfx + "self_attention.out_proj.weight"], sd[pfx + "self_attention.out_proj.bias"],
                            heads, robust, Q)
+    Bn, S, D = x.shape
+    a = _drop(a.reshape(Bn * S, D), drop, 3 * layer).reshape(Bn, S, D)
     x = a + x
     if capture is not None:
         capture[tag + ".attn_out"] = x.detach().clone()
     y = Q(layer_norm(x, sd[pfx + "ln_2.weight"], sd[pfx + "ln_2.bias"], eps), "xn")
     u = y @ Q(sd[pfx + "mlp.0.weight"], "w").t() + sd[pfx + "mlp.0.bias"]
     h = Q(gelu_erf(u), "h")
+    h = _drop(h.reshape(Bn * S, -1), drop, 3 * layer + 1).reshape(Bn, S, -1)
     y = h @ Q(sd[pfx + "mlp.3.weight"], "w").t() + sd[pfx + "mlp.3.bias"]
+    y = _drop(y.reshape(Bn * S, D), drop, 3 * layer + 2).reshape(Bn, S, D)
     return x + y
 
 
 def vit_forward(sd: Dict[str, Tensor], img: Tensor, *, patch_size: int, num_heads: int,
                 robust: bool = False, emulate_bf16=False, eps: float = 1e-6,
-                capture: Optional[dict] = None) -> Tensor:
-    """VisionTransformer.forward, vit.py:335-351."""
+                capture: Optional[dict] = None, drop=None) -> Tensor:
+    """VisionTransformer.forward, vit.py:335-351.  `drop` = (p, keep(site, shape)): training-mode dropout with given masks
+    (site -1: the encoder input [B, S, D], vit.py:175; the blocks' sites: encoder_block)."""
     Q = _Q(emulate_bf16)
     w = sd["conv_proj.weight"]
     D = w.shape[0]
@@ -99,11 +116,12 @@ def vit_forward(sd: Dict[str, Tensor], img: Tensor, *, patch_size: int, num_head
     B = x.shape[0]
     x = torch.cat([sd["class_token"].expand(B, -1, -1), x], dim=1)
     x = x + sd["encoder.pos_embedding"]
+    x = _drop(x, drop, -1)
     if capture is not None:
         capture["embed"] = x.detach().clone()
     i = 0
     while f"encoder.layers.encoder_layer_{i}.ln_1.weight" in sd:
-        x = encoder_block(x, sd, f"encoder.layers.encoder_layer_{i}.", num_heads, robust, Q, eps, capture, f"layer{i}")
+        x = encoder_block(x, sd, f"encoder.layers.encoder_layer_{i}.", num_heads, robust, Q, eps, capture, f"layer{i}", drop, i)
         if capture is not None:
             capture[f"layer{i}.out"] = x.detach().clone()
         i += 1

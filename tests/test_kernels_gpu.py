@@ -886,6 +886,33 @@ def test_sinkhorn_module_forward_backward(dev, shape, iters):
     assert rel < 2e-4, rel
 
 
+@pytest.mark.parametrize("n", [8, 4096, 197 * 768 * 3])
+def test_dropout_kernels(dev, n):
+    """nrv_dropout_add_f32 / nrv_mask_mul_bf16 against the definition, bit for bit (one multiplication, one addition per element);
+    in-place use; masks that are neither 0 nor 1 count as kept."""
+    k = _k()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).to(dev); y = torch.randn(n, generator=g).to(dev)
+    keep = (torch.rand(n, generator=g) >= 0.3).to(torch.uint8)
+    keep[::7] *= 5                                         # any non-zero byte keeps
+    keep = keep.to(dev)
+    scale = 1.0 / 0.7
+    out = k.dropout_add(x, y, keep, scale)
+    ref = x + torch.where(keep != 0, y * torch.tensor(scale, dtype=torch.float32, device=dev), torch.zeros_like(y))
+    assert torch.equal(out, ref)
+    yy = y.clone()
+    assert k.dropout_add(x, yy, keep, scale, out=yy) is yy and torch.equal(yy, ref)
+    a = torch.randn(n, generator=g).to(dev).bfloat16()
+    m = k.mask_mul(a, keep, scale)
+    mref = torch.where(keep != 0, a.float() * torch.tensor(scale, dtype=torch.float32, device=dev), torch.zeros(n, device=dev)).bfloat16()
+    assert torch.equal(m, mref)
+    aa = a.clone()
+    k.mask_mul(aa, keep, scale, out=aa)
+    assert torch.equal(aa, mref)
+    with pytest.raises(Exception):
+        k.mask_mul(a[:-1], keep[:-1], scale)               # n % 8
+
+
 def test_gemms_planned_for_fewer_cus_stay_correct(dev):
     """nrv_set_reserved_cus: with CUs left to a collective the persistent NT grid and the TN split count shrink; results stay
     within the same bounds (NT: same K order, bit-identical; TN: another split count, another summation order)."""

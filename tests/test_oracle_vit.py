@@ -31,15 +31,23 @@ class TorchVT(nn.Module):
         self.ln = nn.LayerNorm(hidden_dim, eps=1e-6)
         self.head = nn.Linear(hidden_dim, num_classes)
 
-    def forward(self, x):
+    def forward(self, x, drop=None):
+        """`drop` = (p, keep(site, shape)): nn.Dropout in training mode (vit.py:100-101,125,175) with GIVEN keep masks, as a
+        multiplication with keep / (1 - p) where the reference has its Dropout modules."""
+        def dr(t, site):
+            if drop is None:
+                return t
+            p, keep = drop
+            return (t.reshape(-1, t.shape[-1]) * (keep(site, (t.numel() // t.shape[-1], t.shape[-1])).to(t.dtype) / (1 - p))).reshape(t.shape) \
+                if site >= 0 else t * (keep(site, tuple(t.shape)).to(t.dtype) / (1 - p))
         n = x.shape[0]
         x = self.conv_proj(x).reshape(n, self.D, -1).permute(0, 2, 1)
-        x = torch.cat([self.class_token.expand(n, -1, -1), x], dim=1) + self.pos
-        for b in self.blocks:
+        x = dr(torch.cat([self.class_token.expand(n, -1, -1), x], dim=1) + self.pos, -1)
+        for i, b in enumerate(self.blocks):
             y = b["ln_1"](x)
             y, _ = b["attn"](y, y, y, need_weights=False)
-            x = x + y
-            y = b["fc2"](torch.nn.functional.gelu(b["fc1"](b["ln_2"](x))))
+            x = x + dr(y, 3 * i)
+            y = dr(b["fc2"](dr(torch.nn.functional.gelu(b["fc1"](b["ln_2"](x))), 3 * i + 1)), 3 * i + 2)
             x = x + y
         return self.head(self.ln(x)[:, 0])
 
@@ -75,6 +83,38 @@ def test_vit_oracle_matches_torch_multihead_attention_stack():
     ref = m(x)
     out = V.vit_forward(sd, x, patch_size=16, num_heads=3)
     assert (out - ref).abs().max() / ref.abs().max() < 5e-6
+
+
+def make_keep(seed: int, p: float):
+    """A reproducible family of keep masks: site -> Bernoulli(1 - p) mask of the asked shape (same seed, same masks)."""
+    def keep(site, shape):
+        g = torch.Generator().manual_seed(seed * 1000 + site + 7)
+        return (torch.rand(shape, generator=g) >= p).to(torch.uint8)
+    return keep
+
+
+def test_vit_oracle_dropout_sites_match_the_torch_module_tree():
+    """Training-mode dropout with injected masks: the oracle's sites (encoder input, attention branch, behind the GELU, behind the
+    second Linear) are where the stock-layer tree has its Dropout modules; logits and gradients agree."""
+    cfg = dict(image_size=64, patch_size=16, num_layers=2, num_heads=3, hidden_dim=96, mlp_dim=192, num_classes=11)
+    sd = V.vit_init_state_dict(seed=3, **cfg)
+    g = torch.Generator().manual_seed(4)
+    for k in sd:
+        if k.endswith("bias") or k == "class_token":
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    m = TorchVT(**cfg)
+    load_into_torch(m, sd)
+    x = torch.randn(3, 3, 64, 64, generator=g)
+    drop = (0.25, make_keep(5, 0.25))
+    ref = m(x, drop)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = V.vit_forward(sdg, x, patch_size=16, num_heads=3, drop=drop)
+    assert (out - ref).abs().max() / ref.abs().max() < 5e-6
+    assert (out - V.vit_forward(sd, x, patch_size=16, num_heads=3)).abs().max() > 1e-3      # the masks do something
+    out.square().sum().backward()
+    ref.square().sum().backward()
+    w = sdg["encoder.layers.encoder_layer_0.mlp.0.weight"].grad
+    assert (w - m.blocks[0]["fc1"].weight.grad).abs().max() < 1e-5 * w.abs().max() + 1e-7
 
 
 def test_patchify_cp1p2_is_conv2d():
