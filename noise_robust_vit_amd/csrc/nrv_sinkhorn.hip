@@ -408,7 +408,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
         }
         lse2[u] = lse2_n[u];
     }
-    dma_image<NP, SKQ_WAVES>(img1, dobase, ldo, N, wave, lane);
+    dma_image<NP, SKQ_WAVES, true>(img1, dobase, ldo, N, wave, lane);      // dO / Q are only read transposed: the V-image swizzle (conflict-free ds_read_b64_tr_b16)
     if (THREE) dma_image<NP, SKQ_WAVES>(vimg, qbase + 2 * p.H * DH, ldq, N, wave, lane);
     // P0 of key tile kt (zero for padded keys / queries): for all tile slots of the wave, or for one
     auto p0_from = [&](const f32x4_t& st, int kt, int u, f32x4_t& out) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
         bf16x8_t imf[2][4], cf[2][TPW];
         auto fetch = [&](int ks, int buf) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) imf[buf][dt] = tr_frag_img(img, u * CH + ks * 32, dt, lane);
+            for (int dt = 0; dt < 4; ++dt) imf[buf][dt] = tr_frag_vimg(img, u * CH + ks * 32, dt, lane);
 #pragma unroll
             for (int s = 0; s < TPW; ++s) {
                 const int ktw = wave + SKQ_WAVES * s;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
     // ---- G = dP7^T = V dO^T.  Every wave is past its dO reads: the dO slot takes Q now (three slots: lands during the walk)
     // or V (two slots: Q follows at the end)
     if (THREE) {
-        dma_image<NP, SKQ_WAVES>(img1, qbase, ldq, N, wave, lane);
+        dma_image<NP, SKQ_WAVES, true>(img1, qbase, ldq, N, wave, lane);
     } else {
         dma_image<NP, SKQ_WAVES>(img1, qbase + 2 * p.H * DH, ldq, N, wave, lane);
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(1024 / TPW, TPW == 1 ? 4 : 2) void sinkhorn_bwd_ker
 
     SK_STAMP();           // 9: dQ
     // ---- dK = dS^T Q  (two slots: Q replaces V now; the last V read was before the walk's barriers)
-    if (!THREE) dma_image<NP, SKQ_WAVES>(img1, qbase, ldq, N, wave, lane);
+    if (!THREE) dma_image<NP, SKQ_WAVES, true>(img1, qbase, ldq, N, wave, lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);        // this wave's part of the Q image; the barrier below publishes all parts
     asm volatile("" ::: "memory");
     f32x4_t dk[TPW][4];

@@ -2,7 +2,7 @@
 # One gpurun call = a sequence of named steps, stopping at the first failure (no GPU step is started behind a failed one).
 #   bash tools/gpu_pass.sh TAG step1 step2 ...       outputs under gpurun_out/TAG/
 # steps: traffic[:ARCH[:BATCH]]  tests[:KEXPR]  bench[:ARCH[:extra flags]]  graphnodes:ARCH  gemmab:LIBS[:only]  stepab:LIBS[:ARCHS]  prof:ARCH  pmcsq:ARCH
-#        py:SCRIPT[:args]  (python tools/SCRIPT args)
+#        py:SCRIPT[:args]  (python tools/SCRIPT args)      prof:ARCH[:extra bench flags[:suffix]]
 set -o pipefail
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -31,16 +31,16 @@ for STEP in "$@"; do
       for a in ${A2:-vit_b_16}; do arch=$a timeout -k 10 400 python tools/step_ab.py $A1 5 6 2>&1 | grep -v amdgpu | tee -a $OUT/stepab.log; RC=$?; [ $RC -ne 0 ] && break; done ;;
     prof)
       A=${A1:-vit_b_16}
-      (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$A -o p -- python3 $ROOT/bench.py --arch $A --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/prof_$A.log 2>&1); RC=$?
-      find $OUT/prof_$A -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$A.csv
-      find $OUT/prof_$A -type f ! -name "*kernel_stats.csv" -delete
-      head -12 $OUT/kernel_stats_$A.csv | cut -c1-200 ;;
+      (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$A${A3:+_$A3} -o p -- python3 $ROOT/bench.py --arch $A $A2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/prof_$A${A3:+_$A3}.log 2>&1); RC=$?
+      find $OUT/prof_$A${A3:+_$A3} -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$A${A3:+_$A3}.csv
+      find $OUT/prof_$A${A3:+_$A3} -type f ! -name "*kernel_stats.csv" -delete
+      head -12 $OUT/kernel_stats_$A${A3:+_$A3}.csv | cut -c1-200 ;;
     pmcsq)
       A=${A1:-vit_b_16}; RC=0
       for SET in "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" \
                  "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
         N=$(echo $SET | cut -d' ' -f1)
-        (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$N -o c -- python3 $ROOT/bench.py --arch $A --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$N.log 2>&1); RC=$?
+        (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$N -o c -- python3 $ROOT/bench.py --arch $A $A2 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$N.log 2>&1); RC=$?
         [ $RC -ne 0 ] && { tail -5 $OUT/pmc_$N.log; break; }
         F=$(find $OUT/pmc_$N -name "*counter_collection.csv" | head -1)
         python tools/pmc_summary.py $F > $OUT/pmc_${N}_summary.txt 2>&1; head -40 $OUT/pmc_${N}_summary.txt
