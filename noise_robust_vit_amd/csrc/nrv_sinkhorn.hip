@@ -60,21 +60,37 @@ __device__ __forceinline__ float ratio_or_zero(float num, float den) { return de
 // reduction finishes -- 10 cross-lane adds for 8 values instead of 32, and one store per value instead of 16 lanes holding the
 // same sum.  Lane (g, qc) ends with the sums of the keys 16 (kt + NT/2 b3) + 4 g + 2 b2 + {0, 1}, b3 = hi8, b2 = hi4:
 // dst = partial-sum row of the wave + 16 kt + that lane offset; the lanes with (lane & 3) == 0 write.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float keep, float send) {
-    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xf, 0xf, false));
-}
+// The selects are in the instructions: `v_add_f32_dpp dst, src, src <pattern> bank_mask:M` writes only the lanes of the banks in M
+// (a bank = 4 consecutive lanes of a row), so "lanes 0-7 take the sum of the pair's first tile, lanes 8-15 that of its second" is two
+// adds, not two selects and an add.  Written as one asm statement (18 cross-lane adds for 8 values): hipcc does not know these are
+// DPP reads, so the statement carries its own wait states (a VALU result needs 2 before a DPP read of it).
 __device__ __forceinline__ void col_sums_pair(const f32x4_t xa, const f32x4_t xb, float* dst, bool hi8, bool hi4, bool writer) {
-    constexpr int ROW_ROR8 = 0x128, HALF_MIRROR = 0x141, QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E;
-    float t4[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) t4[e] = dpp_add<ROW_ROR8>(hi8 ? xb[e] : xa[e], hi8 ? xa[e] : xb[e]);
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        float v = dpp_add<HALF_MIRROR>(hi4 ? t4[e + 2] : t4[e], hi4 ? t4[e] : t4[e + 2]);
-        v = dpp_add<QUAD_XOR1>(v, v);
-        v = dpp_add<QUAD_XOR2>(v, v);
-        if (writer) dst[e] = v;
+    (void)hi8; (void)hi4;               // where a lane's sums belong is in `dst` (the caller's lane offset)
+    float t0, t1, t2, t3, u0, u1;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"       // lanes 8-15: the pair's second tile
+        "v_add_f32_dpp %1, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   // lanes 4-7, 12-15: elements 2, 3
+        "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(u0), "=&v"(u1)
+        : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]));
+    if (writer) {
+        dst[0] = u0;
+        dst[1] = u1;
     }
 }
 
@@ -94,8 +110,10 @@ __device__ __forceinline__ void softmax_tile(const char* kimg, const bf16x8_t (&
     for (int kt = 0; kt < NP / 16; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int key = kt * 16 + 4 * g + e;
-            const float v = key < N ? p0[kt][e] * sc : -INFINITY;
+            // padded keys (>= N) can only sit in the last two key tiles (NP - N < 32): a mask on every tile costs a hoisted SGPR
+            // pair each, parked in VGPR lanes and read back (v_readlane) for every head
+            float v = p0[kt][e] * sc;
+            if (kt >= NP / 16 - 2) v = (kt * 16 + 4 * g + e < N) ? v : -INFINITY;
             p0[kt][e] = v;
             m = fmaxf(m, v);
         }
