@@ -105,6 +105,8 @@ __device__ __forceinline__ void softmax_tile(const char* kimg, const bf16x8_t (&
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) p0[kt] = mfma16(row_frag_img(kimg, kt * 16, ks, lane), qf[ks], p0[kt]);
     }
+    // the row maximum is taken on the raw scores (sc > 0) and the scale folded into the exponent's fma; the row sum is gathered in
+    // four packed accumulators: one instruction per element less in each loop
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NP / 16; ++kt)
@@ -112,22 +114,20 @@ __device__ __forceinline__ void softmax_tile(const char* kimg, const bf16x8_t (&
         for (int e = 0; e < 4; ++e) {
             // padded keys (>= N) can only sit in the last two key tiles (NP - N < 32): a mask on every tile costs a hoisted SGPR
             // pair each, parked in VGPR lanes and read back (v_readlane) for every head
-            float v = p0[kt][e] * sc;
-            if (kt >= NP / 16 - 2) v = (kt * 16 + 4 * g + e < N) ? v : -INFINITY;
-            p0[kt][e] = v;
-            m = fmaxf(m, v);
+            if (kt >= NP / 16 - 2) p0[kt][e] = (kt * 16 + 4 * g + e < N) ? p0[kt][e] : -INFINITY;
+            m = fmaxf(m, p0[kt][e]);
         }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
+    m *= sc;
+    f32x4_t l4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NP / 16; ++kt)
+    for (int kt = 0; kt < NP / 16; ++kt) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float pv = __builtin_amdgcn_exp2f(p0[kt][e] - m);
-            p0[kt][e] = pv;
-            l += pv;
-        }
+        for (int e = 0; e < 4; ++e) p0[kt][e] = __builtin_amdgcn_exp2f(fmaf(p0[kt][e], sc, -m));
+        l4 += p0[kt];
+    }
+    float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = q_ok ? 1.0f / l : 0.f;        // padded query rows contribute nothing to column sums
