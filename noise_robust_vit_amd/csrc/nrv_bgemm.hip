@@ -11,7 +11,8 @@
 //
 // One workgroup (4 waves) per 64 x 64 tile of C, K-steps of 32: both operands are staged into [64][32] bf16 row images (k contiguous,
 // rows padded to 80 bytes; 16-byte loads along the operand's unit stride where its addresses allow, else element by element), wave w owns rows 16 w .. 16 w + 15 of the tile and all 64 columns
-// (4 MFMA 16x16x32 accumulators).  Not tuned: the HBM-bound Sinkhorn sweeps over the materialised matrices dominate this path.
+// (4 MFMA 16x16x32 accumulators).  The vector path keeps its per-item addresses across the K loop and issues the next K-step's loads before
+// the current MFMAs; it streams the fp32 [N, N] operands at ~2.5 TB/s (profiles/r04_robust_composed_path_timing.txt).
 #include "nrv_common.hpp"
 
 namespace {
