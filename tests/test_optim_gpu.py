@@ -261,3 +261,21 @@ def test_weight_gradients_on_the_side_stream_follow_the_one_stream_trajectory(de
         assert torch.equal(results[mode][1], base[1]), mode
         for k, v in base[2].items():
             assert torch.equal(results[mode][2][k], v), (mode, k)
+
+
+def test_captured_step_with_dropout_draws_fresh_masks_per_replay(dev):
+    """`VisionTransformer(dropout=p)` under `Trainer.capture`: the keep masks come from torch's device generator, whose state a HIP
+    graph advances per replay -- with lr = 0 the weights stay and only the masks can change the loss from replay to replay."""
+    from noise_robust_vit_amd import VisionTransformer
+    from noise_robust_vit_amd.train import Trainer, TrainConfig
+    torch.manual_seed(0)
+    m = VisionTransformer(image_size=64, patch_size=16, num_layers=2, num_heads=3, hidden_dim=192, mlp_dim=768, num_classes=10, dropout=0.1)
+    torch.nn.init.normal_(m.heads.head.weight, std=0.02)
+    m = m.to(dev).train()
+    tr = Trainer(m, TrainConfig(lr=0.0, grad_max_norm=5.0), None)
+    x = torch.randn(8, 3, 64, 64, device=dev).bfloat16()
+    y = torch.randint(0, 10, (8,), device=dev)
+    tr.capture(x, y)
+    losses = [tr.step(x, y).item() for _ in range(4)]
+    assert all(l == l for l in losses) and len(set(losses)) > 1, losses
+
