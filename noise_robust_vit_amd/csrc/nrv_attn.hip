@@ -71,19 +71,23 @@ void set_layout(AttnParams& p, int layout, int dh) {
 //     S phase is 2x slower; with lgkmcnt(0) after every read, as in the thin-wave kernel above, the whole head is).
 // Measured on MI355X (ViT-B/16, B = 256, N = 197): see DESIGN.md.
 // ---------------------------------------------------------------------------------------------
-constexpr int ATF_THREADS = 256;
-constexpr int ATF_WAVES = 4;
+// Waves per workgroup: 4, except for heads of at most 64 / 32 tokens (MAE's 50-token encoder): a wave owns 32 rows, so a head of
+// N <= 64 keeps only 2 (N <= 32: 1) of 4 waves busy while the idle ones still take registers -- at 3 waves per SIMD that halves the
+// heads a CU has in flight, and these kernels are latency-bound per head.  Such heads get workgroups of 2 (1) waves.
+template <int NT>
+constexpr int atf_waves() { return NT <= 2 ? 1 : NT <= 4 ? 2 : 4; }
 
 // NT = number of 16-key tiles = image rows / 16.  N = 196 / 197 => NT = 13: 2 x 13 x 2 KiB = 53,248 B of LDS, THREE
 // workgroups per CU (with rows padded to 32 it would be 57,344 B and two).
 template <int NT>
-__global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_fwd_fat_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64 * atf_waves<NT>(), NT <= 13 ? 3 : 2) void attn_fwd_fat_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = NT * 16;                // image rows
     constexpr int IMG = NP * 128;              // one image
     constexpr int NS = (NT + 1) / 2;           // 32-key steps of P.V (the last one is half empty when NT is odd)
     constexpr int NJ = 2 * NP / 8;             // DMA instructions (1 KiB = 8 rows each): K rows then V rows
-    constexpr int JPW = NJ / ATF_WAVES;        // = NT
+    constexpr int ATF_WAVES = atf_waves<NT>();
+    constexpr int JPW = NJ / ATF_WAVES;        // = NT with four waves
     constexpr int MT = (NT == 13 || NT == 14) ? 1 : 2;   // trailing key tiles that can hold padding rows (launch_fwd_fat rounds other counts up to even)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, H = p.H;
@@ -279,11 +283,12 @@ template <int NT>
 __device__ __forceinline__ void dma_two_images(char* smem, const bf16_t* src0, long long ld0, const bf16_t* src1, long long ld1,
                                                int N, int wave, int lane) {
     constexpr int NP = NT * 16;
+    constexpr int PW = 4 * NT / atf_waves<NT>();    // 2 * NP / 8 = 4 NT instructions over the workgroup's waves
     const __amdgpu_buffer_rsrc_t r0 = make_rsrc(src0, 0x7fffffffull), r1 = make_rsrc(src1, 0x7fffffffull);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // scalar: the descriptor select below must stay in SGPRs
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {                  // 2 * NP / 8 = 4 NT instructions, NT per wave
-        const int j = wave_u * NT + i;
+    for (int i = 0; i < PW; ++i) {
+        const int j = wave_u * PW + i;
         const bool second = j >= NP / 8;
         const int r = 8 * (second ? j - NP / 8 : j) + (lane >> 3);
         const int pos = lane & 7;
@@ -295,8 +300,9 @@ __device__ __forceinline__ void dma_two_images(char* smem, const bf16_t* src0, l
 }
 
 template <int NT>
-__global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64 * atf_waves<NT>(), NT <= 13 ? 3 : 2) void attn_bwd_dq_fat_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ATF_WAVES = atf_waves<NT>();
     constexpr int NP = NT * 16;
     constexpr int NS = (NT + 1) / 2;
     constexpr int MT = (NT == 13 || NT == 14) ? 1 : 2;
@@ -420,8 +426,9 @@ __global__ __launch_bounds__(ATF_THREADS, NT <= 13 ? 3 : 2) void attn_bwd_dq_fat
 }
 
 template <int NT>
-__global__ __launch_bounds__(ATF_THREADS, 2) void attn_bwd_dkv_fat_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64 * atf_waves<NT>(), 2) void attn_bwd_dkv_fat_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ATF_WAVES = atf_waves<NT>(), ATF_THREADS = 64 * ATF_WAVES;
     constexpr int NP = NT * 16;
     constexpr int NS = (NT + 1) / 2;
     constexpr int NPS = NS * 32;                       // lse / delta arrays cover whole 32-query steps
@@ -557,7 +564,7 @@ int launch_fwd_fat_nt(const AttnParams& p, hipStream_t s) {
     static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_fat_kernel<NT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != 0) return attr;
-    hipLaunchKernelGGL((attn_fwd_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATF_THREADS), lds, s, p);
+    hipLaunchKernelGGL((attn_fwd_fat_kernel<NT>), dim3(p.B * p.H), dim3(64 * atf_waves<NT>()), lds, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }
@@ -586,9 +593,9 @@ int launch_bwd_fat_nt(const AttnParams& p, hipStream_t s) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
     if (a1 != 0) return a1;
     if (a2 != 0) return a2;
-    hipLaunchKernelGGL((attn_bwd_dq_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATF_THREADS), lds_dq, s, p);
+    hipLaunchKernelGGL((attn_bwd_dq_fat_kernel<NT>), dim3(p.B * p.H), dim3(64 * atf_waves<NT>()), lds_dq, s, p);
     NRV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_fat_kernel<NT>), dim3(p.B * p.H), dim3(ATF_THREADS), lds_dkv, s, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_fat_kernel<NT>), dim3(p.B * p.H), dim3(64 * atf_waves<NT>()), lds_dkv, s, p);
     NRV_CHECK_LAUNCH();
     return 0;
 }
