@@ -68,6 +68,33 @@ __device__ __forceinline__ void load_tile(char* img, const bf16_t* src, long lon
     }
 }
 
+// the same tile in two halves: global -> registers (issued a tile ahead, in flight during the current tile's arithmetic), registers -> LDS.
+// A thread holds KS 16-byte chunks of a tile (64 rows x 4 KS chunks over 256 threads).
+template <int KS>
+__device__ __forceinline__ void fetch_tile(u32x4_t (&v)[KS], const bf16_t* src, long long ld, int r0, int N, int dh, int tid) {
+    using C = GenCfg<KS>;
+    constexpr int CPR = C::DHP / 8;
+    static_assert(GT * CPR / GEN_THREADS == KS, "chunks per thread");
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        const int idx = i * GEN_THREADS + tid;
+        const int r = idx / CPR, c = idx - r * CPR;
+        v[i] = u32x4_t{0u, 0u, 0u, 0u};
+        if (r0 + r < N && c * 8 < dh) v[i] = *reinterpret_cast<const u32x4_t*>(src + (long long)(r0 + r) * ld + c * 8);
+    }
+}
+template <int KS>
+__device__ __forceinline__ void put_tile(char* img, const u32x4_t (&v)[KS], int tid) {
+    using C = GenCfg<KS>;
+    constexpr int CPR = C::DHP / 8;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        const int idx = i * GEN_THREADS + tid;
+        const int r = idx / CPR, c = idx - r * CPR;
+        *reinterpret_cast<u32x4_t*>(img + tile_off<KS>(r, c)) = v[i];
+    }
+}
+
 // row fragment (A or B operand whose 16 rows are tile rows rb .. rb + 15): lane -> row rb + (lane & 15), k = 32 ks + 8 (lane >> 4) ..
 template <int KS>
 __device__ __forceinline__ bf16x8_t row_frag(const char* img, int rb, int ks, int lane) {
@@ -128,11 +155,18 @@ __global__ __launch_bounds__(GEN_THREADS) void attn_gen_fwd_kernel(const GenPara
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    u32x4_t kreg[KS], vreg[KS];                           // the next K / V tile, requested one tile ahead
+    fetch_tile<KS>(kreg, kbase, ldq, 0, N, dh, tid);
+    fetch_tile<KS>(vreg, vbase, ldq, 0, N, dh, tid);
     for (int k0 = 0; k0 < N; k0 += GT) {
         __syncthreads();                                  // every wave is done with the previous tile
-        load_tile<KS>(kimg, kbase, ldq, k0, N, dh, tid);
-        load_tile<KS>(vimg, vbase, ldq, k0, N, dh, tid);
+        put_tile<KS>(kimg, kreg, tid);
+        put_tile<KS>(vimg, vreg, tid);
         __syncthreads();
+        if (k0 + GT < N) {
+            fetch_tile<KS>(kreg, kbase, ldq, k0 + GT, N, dh, tid);
+            fetch_tile<KS>(vreg, vbase, ldq, k0 + GT, N, dh, tid);
+        }
         // S^T = K Q^T for the four 16-key sub-tiles; lane: keys k0 + 16 sub + 4 g + e of query q
         f32x4_t st[4];
         float tmax = -INFINITY;
@@ -226,11 +260,18 @@ __global__ __launch_bounds__(GEN_THREADS) void attn_gen_dq_kernel(const GenParam
     f32x4_t dqt[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dqt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    u32x4_t kreg[KS], vreg[KS];                           // the next K / V tile, requested one tile ahead
+    fetch_tile<KS>(kreg, kbase, ldq, 0, N, dh, tid);
+    fetch_tile<KS>(vreg, vbase, ldq, 0, N, dh, tid);
     for (int k0 = 0; k0 < N; k0 += GT) {
         __syncthreads();
-        load_tile<KS>(kimg, kbase, ldq, k0, N, dh, tid);
-        load_tile<KS>(vimg, vbase, ldq, k0, N, dh, tid);
+        put_tile<KS>(kimg, kreg, tid);
+        put_tile<KS>(vimg, vreg, tid);
         __syncthreads();
+        if (k0 + GT < N) {
+            fetch_tile<KS>(kreg, kbase, ldq, k0 + GT, N, dh, tid);
+            fetch_tile<KS>(vreg, vbase, ldq, k0 + GT, N, dh, tid);
+        }
         f32x4_t ds[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -301,16 +342,42 @@ __global__ __launch_bounds__(GEN_THREADS) void attn_gen_dkv_kernel(const GenPara
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dkt[dt] = dvt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int q0 = 0; q0 < N; q0 += GT) {
-        __syncthreads();
-        load_tile<KS>(qimg, qbase, ldq, q0, N, dh, tid);
-        load_tile<KS>(doimg, dobase, ldo, q0, N, dh, tid);
+    u32x4_t qreg[KS], doreg[KS];                          // the next Q / dO tile and its statistics, requested one tile ahead
+    float lreg = INFINITY, dreg = 0.f;
+    auto fetch_stats = [&](int q0) {
         if (tid < GT) {
             const int qq = q0 + tid;
-            lse2s[tid] = qq < N ? lse[qq] * LOG2E : INFINITY;        // exp2(s - inf) = 0 for padded queries
-            dels[tid] = qq < N ? delta[qq] : 0.f;
+            lreg = qq < N ? lse[qq] * LOG2E : INFINITY;              // exp2(s - inf) = 0 for padded queries
+            dreg = qq < N ? delta[qq] : 0.f;
+        }
+    };
+    // one tile ahead only where the registers are there: at head dims <= 64 the prefetch registers cost this kernel half its
+    // occupancy (82 -> 128 VGPRs) and 17 % of its time (profiles/r04_streaming_attention_prefetch.txt)
+    constexpr bool AHEAD = KS >= 3;
+    if (AHEAD) {
+        fetch_tile<KS>(qreg, qbase, ldq, 0, N, dh, tid);
+        fetch_tile<KS>(doreg, dobase, ldo, 0, N, dh, tid);
+        fetch_stats(0);
+    }
+    for (int q0 = 0; q0 < N; q0 += GT) {
+        __syncthreads();
+        if (!AHEAD) {
+            fetch_tile<KS>(qreg, qbase, ldq, q0, N, dh, tid);
+            fetch_tile<KS>(doreg, dobase, ldo, q0, N, dh, tid);
+            fetch_stats(q0);
+        }
+        put_tile<KS>(qimg, qreg, tid);
+        put_tile<KS>(doimg, doreg, tid);
+        if (tid < GT) {
+            lse2s[tid] = lreg;
+            dels[tid] = dreg;
         }
         __syncthreads();
+        if (AHEAD && q0 + GT < N) {
+            fetch_tile<KS>(qreg, qbase, ldq, q0 + GT, N, dh, tid);
+            fetch_tile<KS>(doreg, dobase, ldo, q0 + GT, N, dh, tid);
+            fetch_stats(q0 + GT);
+        }
         f32x4_t pt[4], ds[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
