@@ -304,7 +304,7 @@ class record_attention:
 
 def _record(qkv: Tensor, aux, B: int, N: int, H: int, dh: int, scale: float, robust: bool) -> None:
     if robust:
-        lse, scal = aux                                   # scalings [B, H, 7, N]: a1 b1 a2 b2 a3 b3 a4
+        lse, scal = aux[0], aux[1]                        # scalings [B, H, 7, N]: a1 b1 a2 b2 a3 b3 a4
         p = K.attn_probs(qkv, lse, B, N, H, dh, scale)
         a, b = scal[:, :, 6], scal[:, :, 5]              # the vectors are cumulative: P = diag(a4) softmax(S) diag(b3)
         p = p * a[..., :, None] * b[..., None, :]
@@ -340,8 +340,9 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
                     epilogue=EPI_BIAS if bqkv is not None else EPI_NONE, bias=bqkv)
     scale = dh ** -0.5
     if meta.robust:                               # robust=True: softmax + Sinkhorn normalisation (utils.py:1025-1037), fused
-        o, lse, scal = K.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale)
-        aux = (lse, scal)
+        p7 = {}                                   # the composed path (N > 256 / dh != 64) hands its P7 to the backward through it
+        o, lse, scal = K.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale, saved=p7)
+        aux = (lse, scal, p7)
     else:
         o, aux = K.attn_fwd(qkv, B, N, H, dh, scale)
     if _RECORDING is not None:
@@ -378,7 +379,7 @@ def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int,
     do = K.gemm_nt(dy16, wo_t, out_dtype=torch.bfloat16)
     scale = dh ** -0.5
     if meta.robust:
-        dqkv = K.attn_sinkhorn_bwd(qkv, do, aux[0], aux[1], B, N, H, dh, scale)
+        dqkv = K.attn_sinkhorn_bwd(qkv, do, aux[0], aux[1], B, N, H, dh, scale, saved=aux[2])
     else:
         dqkv = K.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
     dwqkv, dbqkv = _dw_db(meta, dqkv, xn, wqkv, bqkv)

@@ -355,15 +355,21 @@ def _sinkhorn_fused_shape(N: int, dh: int) -> bool:
     return dh == 64 and N <= 256
 
 
-def attn_sinkhorn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
+# composed robust attention: the forward's normalised matrix P7 [B,H,N,N] fp32 is handed to the backward (which otherwise recomputes it:
+# the scores GEMM + 5 passes over the matrix) when it is at most this many bytes per layer -- 288 GB of HBM are there to be used
+SINKHORN_KEEP_P_BYTES = 2 << 30
+
+
+def attn_sinkhorn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float, saved: Optional[dict] = None):
     """robust=True attention (utils.py:1025-1037): returns (out bf16, lse fp32 [B,H,N], scalings fp32 [B,H,7,N]).
     N <= 256 and dh == 64: the fused kernel.  Any other shape (vit_h_14, 384-px checkpoints, other head dims): composed from
-    the batched GEMM and the stand-alone Sinkhorn op on materialised [B,H,N,N] scores -- the reference's own structure."""
+    the batched GEMM and the stand-alone Sinkhorn op on materialised [B,H,N,N] scores -- the reference's own structure.
+    `saved` (a dict the caller keeps for the backward and passes to attn_sinkhorn_bwd): the composed path leaves P7 in it."""
     _bf16(qkv, "qkv")
     if not qkv.is_contiguous() or qkv.numel() != B * N * 3 * H * dh:
         raise NrvError("attn_sinkhorn_fwd: qkv must be contiguous [B*N, 3*H*dh]")
     if not _sinkhorn_fused_shape(N, dh):
-        return _attn_sinkhorn_fwd_composed(qkv, B, N, H, dh, scale)
+        return _attn_sinkhorn_fwd_composed(qkv, B, N, H, dh, scale, saved)
     out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     scal = torch.empty(B, H, 7, N, dtype=torch.float32, device=qkv.device)
@@ -375,12 +381,13 @@ def attn_sinkhorn_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float
     return out, lse, scal
 
 
-def attn_sinkhorn_bwd(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+def attn_sinkhorn_bwd(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: int, N: int, H: int, dh: int, scale: float,
+                      saved: Optional[dict] = None) -> Tensor:
     _bf16(qkv, "qkv"); _bf16(dout, "dout"); _f32(lse, "lse"); _f32(scal, "scal")
     if not (qkv.is_contiguous() and dout.is_contiguous()):
         raise NrvError("attn_sinkhorn_bwd: operands must be contiguous")
     if not _sinkhorn_fused_shape(N, dh):
-        return _attn_sinkhorn_bwd_composed(qkv, dout, lse, scal, B, N, H, dh, scale)
+        return _attn_sinkhorn_bwd_composed(qkv, dout, lse, scal, B, N, H, dh, scale, saved)
     dqkv = torch.empty_like(qkv)
     lib = _lib.load()
     _run("attn_sinkhorn_bwd", 10.0 * B * H * N * N * dh, 2 * B * N * H * dh * 7,
@@ -423,7 +430,7 @@ def _sinkhorn_scores(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float)
     return S
 
 
-def _attn_sinkhorn_fwd_composed(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float):
+def _attn_sinkhorn_fwd_composed(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float, saved: Optional[dict] = None):
     W = 3 * H * dh
     rs, cs, bs, hs = _head_strides(H, dh, W, N)
     S = _sinkhorn_scores(qkv, B, N, H, dh, scale)
@@ -437,17 +444,22 @@ def _attn_sinkhorn_fwd_composed(qkv: Tensor, B: int, N: int, H: int, dh: int, sc
     scal = torch.empty(B, H, 7, N, dtype=torch.float32, device=qkv.device)
     scal[:, :, 0::2] = avec.reshape(B, H, 4, N)
     scal[:, :, 1::2] = bvec.reshape(B, H, 3, N)
+    if saved is not None and P.numel() * 4 <= SINKHORN_KEEP_P_BYTES:
+        saved["P7"] = P
     return out, lse.reshape(B, H, N), scal
 
 
-def _attn_sinkhorn_bwd_composed(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+def _attn_sinkhorn_bwd_composed(qkv: Tensor, dout: Tensor, lse: Tensor, scal: Tensor, B: int, N: int, H: int, dh: int, scale: float,
+                                saved: Optional[dict] = None) -> Tensor:
     W = 3 * H * dh
     rs, cs, bs, hs = _head_strides(H, dh, W, N)
     ors, ocs, obs, ohs = _head_strides(H, dh, H * dh, N)
     mat = (N, 1, H * N * N, N * N)                                 # a [B,H,N,N] fp32 matrix
     matT = (1, N, H * N * N, N * N)                                # ... read transposed
-    S = _sinkhorn_scores(qkv, B, N, H, dh, scale)                  # recomputed: nothing [N,N]-sized is kept between the passes
-    P, _, _, _ = sinkhorn_fwd(S, iters=3)
+    S = _sinkhorn_scores(qkv, B, N, H, dh, scale)                  # recomputed (one GEMM): the Sinkhorn backward rebuilds P0 from it
+    P = saved.pop("P7", None) if saved is not None else None       # the forward's matrix when it was small enough to keep
+    if P is None:
+        P, _, _, _ = sinkhorn_fwd(S, iters=3)
     avec = scal[:, :, 0::2].reshape(B * H, 4, N).contiguous()
     bvec = scal[:, :, 1::2].reshape(B * H, 3, N).contiguous()
     dqkv = torch.empty_like(qkv)
