@@ -256,9 +256,12 @@ int nrv_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
  * The keep mask is the caller's data: one byte per element (0 = dropped), n % 8 == 0, 8-byte aligned; scale = 1 / (1 - p).
  *   nrv_dropout_add_f32:  out = x + y * (keep ? scale : 0)   fp32 residual stream x, fp32 branch output y (out may alias x or y)
  *   nrv_mask_mul_bf16:    out = a * (keep ? scale : 0)       bf16 (out may alias a): GELU output, gelu' stream, branch gradient
- * attention_dropout (inside the attention kernels) is not implemented: the modules raise for it. */
+ *   nrv_mask_mul_f32:     the same on fp32, any n: attention_dropout (vit.py:108, utils.py dropout on the attention weights) is
+ *                         COMPOSED -- scores (nrv_bgemm), softmax / Sinkhorn on the materialised matrix (nrv_sinkhorn_fwd), this mask,
+ *                         P v (nrv_bgemm) -- not fused into the attention kernels: correct, and as slow as materialising [B,H,N,N]. */
 int nrv_dropout_add_f32(const float* x, const float* y, const unsigned char* keep, float* out, float scale, int64_t n, void* stream);
 int nrv_mask_mul_bf16(const void* a_bf16, const unsigned char* keep, void* out_bf16, float scale, int64_t n, void* stream);
+int nrv_mask_mul_f32(const float* a, const unsigned char* keep, float* out, float scale, int64_t n, void* stream);
 
 /* Row gather / scatter-add of the residual stream (MAE token selection, mae.py:75-76 and its backward):
  *   fwd: out[r, :] = src[index[r], :]   (rows_out rows, dim % 4 == 0, fp32; src has rows_src rows)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "nrv_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nrv_dropout_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "nrv_mask_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "nrv_mask_mul_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "nrv_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "nrv_scatter_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "nrv_sumsq_workspace": (c_size_t, [c_int64]),

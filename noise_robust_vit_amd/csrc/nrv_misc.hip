@@ -183,6 +183,13 @@ __global__ __launch_bounds__(256) void mask_mul_kernel(const bf16_t* __restrict_
     }
 }
 
+// the fp32 form (attention probabilities [B,H,N,N] of the composed attention-dropout path: any element count, not a hot path)
+__global__ __launch_bounds__(256) void mask_mul_f32_kernel(const float* __restrict__ a, const unsigned char* __restrict__ keep,
+                                                           float* __restrict__ out, float scale, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = keep[i] ? a[i] * scale : 0.f;
+}
+
 // rows of the fp32 residual stream: gather out[r] = src[index[r]]; scatter dsrc[index[r]] = dout[r].  The indices are device data
 // (a permutation computed by the caller's kernels): an index outside [0, rows_src) can never become an address -- the gather
 // writes a zero row for it, the scatter drops the row (ABI 11; the host cannot validate device data without a sync).
@@ -331,6 +338,15 @@ extern "C" int nrv_mask_mul_bf16(const void* a_bf16, const unsigned char* keep, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mask_mul_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, s, static_cast<const bf16_t*>(a_bf16), keep,
                        static_cast<bf16_t*>(out_bf16), scale, (long long)(n >> 3));
+    NRV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nrv_mask_mul_f32(const float* a, const unsigned char* keep, float* out, float scale, int64_t n, void* stream) {
+    if (!a || !keep || !out) return NRV_ERR_NULL;
+    if (n <= 0) return NRV_ERR_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mask_mul_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, a, keep, out, scale, (long long)n);
     NRV_CHECK_LAUNCH();
     return 0;
 }

@@ -134,6 +134,8 @@ class BlockMeta:
     # oracle uses; default: torch's device generator).  Sites of layer i: 3 i (attention branch), 3 i + 1 (GELU output), 3 i + 2 (MLP branch).
     dropout: float = 0.0
     mask_source: Optional[object] = None
+    # dropout on the attention weights (vit.py:108): composed on the materialised [B,H,N,N] matrix (kernels.attn_dropout_fwd), site -(2 + i)
+    attn_dropout: float = 0.0
 
 
 def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
@@ -316,17 +318,17 @@ def _record(qkv: Tensor, aux, B: int, N: int, H: int, dh: int, scale: float, rob
 # ----------------------------------------------------------------------------------------------
 # attention half
 # ----------------------------------------------------------------------------------------------
-def draw_keep(meta: BlockMeta, site: int, shape, device) -> Tensor:
-    """uint8 keep mask of one dropout site (1 = kept)."""
+def draw_keep(meta: BlockMeta, site: int, shape, device, p: Optional[float] = None) -> Tensor:
+    """uint8 keep mask of one dropout site (1 = kept); p defaults to the stack's `dropout`."""
     if meta.mask_source is not None:
         m = meta.mask_source(site, tuple(shape))
         if m.dtype != torch.uint8 or tuple(m.shape) != tuple(shape):
             raise NrvError(f"mask_source({site}): expected a uint8 mask of shape {tuple(shape)}")
         return m.to(device).contiguous()
-    return (torch.rand(shape, device=device) >= meta.dropout).to(torch.uint8)
+    return (torch.rand(shape, device=device) >= (meta.dropout if p is None else p)).to(torch.uint8)
 
 
-def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, drop=None):
+def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual: bool, drop=None, adrop=None):
     """x fp32 [B*N, D] -> (y fp32 [B*N, D], saved).  `ln_w is None`: no LayerNorm in front of the projection (the bare
     `MultiheadAttention.forward` of the reference's forked module, utils.py:741-751)."""
     H, dh = meta.heads, meta.dim_head
@@ -339,13 +341,18 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
     qkv = K.gemm_nt(xn, wqkv_b, out_dtype=torch.bfloat16,
                     epilogue=EPI_BIAS if bqkv is not None else EPI_NONE, bias=bqkv)
     scale = dh ** -0.5
-    if meta.robust:                               # robust=True: softmax + Sinkhorn normalisation (utils.py:1025-1037), fused
+    if adrop is not None:                         # dropout on the attention weights: the composed path (materialised matrix), softmax or Sinkhorn
+        pscale, asite, pa = adrop
+        akeep = draw_keep(meta, asite, (B, H, N, N), x.device, p=pa)
+        o, asaved = K.attn_dropout_fwd(qkv, B, N, H, dh, scale, meta.robust, akeep, pscale)
+        aux = ("attn_dropout", asaved)
+    elif meta.robust:                             # robust=True: softmax + Sinkhorn normalisation (utils.py:1025-1037), fused
         p7 = {}                                   # the composed path (N > 256 / dh != 64) hands its P7 to the backward through it
         o, lse, scal = K.attn_sinkhorn_fwd(qkv, B, N, H, dh, scale, saved=p7)
         aux = (lse, scal, p7)
     else:
         o, aux = K.attn_fwd(qkv, B, N, H, dh, scale)
-    if _RECORDING is not None:
+    if _RECORDING is not None and adrop is None:
         _record(qkv, aux, B, N, H, dh, scale, meta.robust)
     keep = None
     if residual and drop is not None:
@@ -378,7 +385,9 @@ def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int,
     dwo, dbo = _dw_db(meta, dy16, o, wo, bo)
     do = K.gemm_nt(dy16, wo_t, out_dtype=torch.bfloat16)
     scale = dh ** -0.5
-    if meta.robust:
+    if isinstance(aux, tuple) and len(aux) == 2 and isinstance(aux[0], str):         # ("attn_dropout", saved)
+        dqkv = K.attn_dropout_bwd(qkv, do, aux[1], B, N, H, dh, scale)
+    elif meta.robust:
         dqkv = K.attn_sinkhorn_bwd(qkv, do, aux[0], aux[1], B, N, H, dh, scale, saved=aux[2])
     else:
         dqkv = K.attn_bwd(qkv, o, do, aux, B, N, H, dh, scale)
@@ -491,9 +500,13 @@ class EncoderStackFn(torch.autograd.Function):
         if not 0.0 <= pdrop < 1.0:
             raise NrvError(f"dropout probability {pdrop} outside [0, 1)")
         scale = 1.0 / (1.0 - pdrop)
+        pattn = float(meta.attn_dropout)
+        if not 0.0 <= pattn < 1.0:
+            raise NrvError(f"attention dropout probability {pattn} outside [0, 1)")
         for i in range(depth):
             p = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            cur, sa = attn_half_fwd(cur, B, N, meta, *p[0:6], residual=True, drop=(scale, 3 * i) if pdrop > 0.0 else None)
+            cur, sa = attn_half_fwd(cur, B, N, meta, *p[0:6], residual=True, drop=(scale, 3 * i) if pdrop > 0.0 else None,
+                                    adrop=(1.0 / (1.0 - pattn), -(2 + i), pattn) if pattn > 0.0 else None)
             cur, sm = mlp_half_fwd(cur, meta, *p[6:12], residual=True, save=train, drop=(scale, 3 * i + 1) if pdrop > 0.0 else None)
             saved.append((sa, sm) if train else None)
         ctx.meta, ctx.params, ctx.saved_blocks, ctx.shape = meta, params, saved, (B, N, D)
@@ -538,7 +551,9 @@ class AttnHalfFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo):
         x2, B, N, D = _as_stream(x)
-        y, saved = attn_half_fwd(x2, B, N, meta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual=False)
+        pa = float(meta.attn_dropout)
+        y, saved = attn_half_fwd(x2, B, N, meta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual=False,
+                                 adrop=(1.0 / (1.0 - pa), -2, pa) if pa > 0.0 else None)
         ctx.meta, ctx.params, ctx.saved_half, ctx.shape = meta, (ln_w, ln_b, wqkv, bqkv, wo, bo), saved, (B, N, D)
         return y.reshape(B, N, wo.shape[0])
 

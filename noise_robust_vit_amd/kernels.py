@@ -556,6 +556,58 @@ def mask_mul(a: Tensor, keep: Tensor, scale: float, out: Optional[Tensor] = None
     return o
 
 
+def mask_mul_f32(a: Tensor, keep: Tensor, scale: float, out: Optional[Tensor] = None) -> Tensor:
+    """out = a * (keep ? scale : 0) on fp32 tensors of any size (include/nrv.h nrv_mask_mul_f32)."""
+    _f32(a, "a"); _dev(keep, "keep")
+    if not a.is_contiguous() or keep.dtype != torch.uint8 or not keep.is_contiguous() or keep.numel() != a.numel():
+        raise NrvError("mask_mul_f32: a contiguous fp32, keep a contiguous uint8 mask with one byte per element")
+    o = torch.empty_like(a) if out is None else out
+    lib = _lib.load()
+    _run("dropout", 0.0, a.numel() * 9,
+         lambda: lib.nrv_mask_mul_f32(a.data_ptr(), keep.data_ptr(), o.data_ptr(), float(scale), a.numel(), _stream()), "nrv_mask_mul_f32")
+    return o
+
+
+def attn_dropout_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float, robust: bool, keep: Tensor, pscale: float):
+    """Attention with dropout ON THE ATTENTION WEIGHTS (attention_dropout > 0: vit.py:108, torch's MultiheadAttention semantics):
+    composed on the materialised matrix like the robust attention beyond the fused shapes -- scores, softmax (the Sinkhorn op with
+    0 iterations) or the Sinkhorn normalisation (robust), the keep mask [B,H,N,N], P v.  Returns (out bf16, saved) with what the
+    backward needs (the dropped matrix, the statistics)."""
+    _bf16(qkv, "qkv")
+    W = 3 * H * dh
+    rs, cs, bs, hs = _head_strides(H, dh, W, N)
+    iters = 3 if robust else 0
+    S = _sinkhorn_scores(qkv, B, N, H, dh, scale)
+    P, lse, avec, bvec = sinkhorn_fwd(S, iters=iters)
+    del S
+    if tuple(keep.shape) != (B, H, N, N):
+        raise NrvError(f"attn_dropout_fwd: keep must be a uint8 mask of shape {(B, H, N, N)}")
+    mask_mul_f32(P, keep, pscale, out=P)
+    out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
+    ors, ocs, obs, ohs = _head_strides(H, dh, H * dh, N)
+    bgemm((P, 0), (N, 1, H * N * N, N * N), (qkv, 2 * H * dh), (rs, cs, bs, hs), (out, 0), (ors, ocs, obs, ohs), B, H, N, dh, N, 1.0)
+    return out, (P, lse, avec, bvec, keep, pscale, iters)
+
+
+def attn_dropout_bwd(qkv: Tensor, dout: Tensor, saved, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
+    Pd, lse, avec, bvec, keep, pscale, iters = saved
+    W = 3 * H * dh
+    rs, cs, bs, hs = _head_strides(H, dh, W, N)
+    ors, ocs, obs, ohs = _head_strides(H, dh, H * dh, N)
+    mat, matT = (N, 1, H * N * N, N * N), (1, N, H * N * N, N * N)
+    dqkv = torch.empty_like(qkv)
+    bgemm((Pd, 0), matT, (dout, 0), (ors, ocs, obs, ohs), (dqkv, 2 * H * dh), (rs, cs, bs, hs), B, H, N, dh, N, 1.0)          # dV = Pd^T dO
+    dP = torch.empty_like(Pd)
+    bgemm((dout, 0), (ors, ocs, obs, ohs), (qkv, 2 * H * dh), (cs, rs, bs, hs), (dP, 0), mat, B, H, N, N, dh, 1.0)           # d(Pd) = dO v^T
+    mask_mul_f32(dP, keep, pscale, out=dP)                                                                                      # dP
+    S = _sinkhorn_scores(qkv, B, N, H, dh, scale)
+    dS = sinkhorn_bwd(S, dP, lse, avec, bvec, iters=iters)
+    del dP, S
+    bgemm((dS, 0), mat, (qkv, H * dh), (rs, cs, bs, hs), (dqkv, 0), (rs, cs, bs, hs), B, H, N, dh, N, scale)
+    bgemm((dS, 0), matT, (qkv, 0), (rs, cs, bs, hs), (dqkv, H * dh), (rs, cs, bs, hs), B, H, N, dh, N, scale)
+    return dqkv
+
+
 def gather_rows(src: Tensor, index: Tensor) -> Tensor:
     """out[r] = src[index[r]]; src fp32 [R, dim], index int64 [rows_out]."""
     _f32(src, "src"); _dev(index, "index")

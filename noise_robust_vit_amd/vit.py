@@ -28,11 +28,6 @@ __all__ = ["VisionTransformer", "Encoder", "EncoderBlock", "MLPBlock", "Multihea
            "vit_s_16", "vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32", "vit_h_14"]
 
 
-def _no_dropout(p: float, what: str) -> None:
-    if p != 0.0:
-        raise NotImplementedError(f"{what}={p}: dropout inside the attention kernels is not implemented (reference default 0); "
-                                  "`dropout` (MLP / residual branches, encoder input) is")
-
 
 def _input_dropout(x: torch.Tensor, meta: BlockMeta, p: float) -> torch.Tensor:
     """Encoder-level dropout on the embedded tokens (vit.py:154,175): once per step, plain tensor ops.  Site -1 of the mask source."""
@@ -81,10 +76,9 @@ class MultiheadAttention(nn.Module):
             raise NotImplementedError("self-attention only (query is key is value), as EncoderBlock calls it")
         if key_padding_mask is not None or attn_mask is not None:
             raise NotImplementedError("attention masks are outside the encoder hot path")
-        if self.training:
-            _no_dropout(self.dropout, "attention dropout")
         x = query if self.batch_first else query.transpose(0, 1)
-        meta = BlockMeta(heads=self.num_heads, dim_head=self.head_dim, eps=0.0, robust=bool(self.robust))
+        meta = BlockMeta(heads=self.num_heads, dim_head=self.head_dim, eps=0.0, robust=bool(self.robust),
+                         attn_dropout=self.dropout if self.training else 0.0, mask_source=getattr(self, "mask_source", None))
         if not need_weights:
             out = AttnHalfFn.apply(x, meta, None, None, *self.attn_params())
             return (out if self.batch_first else out.transpose(0, 1)), None
@@ -148,14 +142,10 @@ class EncoderBlock(nn.Module):
         return ([self.ln_1.weight, self.ln_1.bias] + self.self_attention.attn_params()
                 + [self.ln_2.weight, self.ln_2.bias] + self.mlp.mlp_params())
 
-    def check_dropout(self):
-        if self.training:
-            _no_dropout(self.self_attention.dropout, "attention_dropout")
-
     def forward(self, input: torch.Tensor):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
-        self.check_dropout()
         self._meta.dropout = self.dropout.p if self.training else 0.0          # vit.py:100-101,125
+        self._meta.attn_dropout = self.self_attention.dropout if self.training else 0.0      # vit.py:108
         return EncoderStackFn.apply(input, self._meta, *self.layer_params())
 
 
@@ -181,9 +171,9 @@ class Encoder(nn.Module):
         """All encoder layers in one autograd node (positional embedding already added, no final LN)."""
         flat = []
         for blk in self.layers:
-            blk.check_dropout()
             flat += blk.layer_params()
         p = self.dropout.p if self.training else 0.0
+        self._meta.attn_dropout = self.layers[0].self_attention.dropout if self.training and len(self.layers) else 0.0      # vit.py:108, one value for all blocks (vit.py:161)
         self._meta.dropout = p                                      # the blocks' MLP / branch dropout (vit.py:100-101,125): same p (vit.py:161)
         if p > 0.0:
             x = _input_dropout(x, self._meta, p)                    # vit.py:175

@@ -42,10 +42,12 @@ def patchify_cp1p2(img: Tensor, p: int) -> Tensor:
 
 
 def mha_self_attention(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor,
-                       heads: int, robust: bool, Q: _Q) -> Tensor:
-    """Self-attention of nn.MultiheadAttention(batch_first=True, need_weights=False), dropout 0.
+                       heads: int, robust: bool, Q: _Q, adrop=None) -> Tensor:
+    """Self-attention of nn.MultiheadAttention(batch_first=True, need_weights=False).
 
     q,k,v = split(x W_in^T + b_in); per head softmax(q k^T / sqrt(dh)) v; concat heads; out_proj.
+    `adrop` = (p, keep [B,H,S,S]): training-mode dropout on the attention weights (F.multi_head_attention_forward applies
+    `dropout(attn)` between the softmax and attn @ v) with a given keep mask; fp32 path only.
     """
     B, S, E = x.shape
     dh = E // heads
@@ -57,8 +59,11 @@ def mha_self_attention(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out
         attn = torch.softmax(dots, dim=-1)
         if robust:
             attn = sinkhorn_normalise(attn)
+        if adrop is not None:
+            attn = attn * (adrop[1].to(attn.dtype) * (1.0 / (1.0 - adrop[0])))
         o = torch.matmul(attn, v)
     else:
+        assert adrop is None, "attention dropout: fp32 oracle only"
         m = dots.max(dim=-1, keepdim=True).values
         p = torch.exp(dots - m)
         l = p.sum(dim=-1, keepdim=True)
@@ -81,16 +86,17 @@ def _drop(t: Tensor, drop, site: int) -> Tensor:
 
 
 def encoder_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, robust: bool, Q: _Q,
-                  eps: float = 1e-6, capture: Optional[dict] = None, tag: str = "", drop=None, layer: int = 0) -> Tensor:
+                  eps: float = 1e-6, capture: Optional[dict] = None, tag: str = "", drop=None, layer: int = 0, attn_drop=None) -> Tensor:
     """EncoderBlock.forward, vit.py:118-130.  `capture[tag + ".attn_out"]` receives the residual stream
     after the attention half (vit.py:126), for the per-half localisation in tests/test_model_gpu.py.  Dropout sites of layer i:
     3 i the attention branch (vit.py:125), 3 i + 1 behind the GELU (vit.py:100), 3 i + 2 behind the second Linear (vit.py:101);
     the masks are over the flattened [batch * tokens, features] matrices."""
     a = Q(layer_norm(x, sd[pfx + "ln_1.weight"], sd[pfx + "ln_1.bias"], eps), "xn")
+    Bn, S, D = x.shape
+    adrop = None if attn_drop is None else (attn_drop[0], attn_drop[1](-(2 + layer), (Bn, heads, S, S)))      # site -(2 + layer), vit.py:108
     a = mha_self_attention(a, sd[pfx + "self_attention.in_proj_weight"], sd[pfx + "self_attention.in_proj_bias"],
                            sd[pfx + "self_attention.out_proj.weight"], sd[pfx + "self_attention.out_proj.bias"],
-                           heads, robust, Q)
-    Bn, S, D = x.shape
+                           heads, robust, Q, adrop)
     a = _drop(a.reshape(Bn * S, D), drop, 3 * layer).reshape(Bn, S, D)
     x = a + x
     if capture is not None:
@@ -106,9 +112,10 @@ def encoder_block(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, robust
 
 def vit_forward(sd: Dict[str, Tensor], img: Tensor, *, patch_size: int, num_heads: int,
                 robust: bool = False, emulate_bf16=False, eps: float = 1e-6,
-                capture: Optional[dict] = None, drop=None) -> Tensor:
+                capture: Optional[dict] = None, drop=None, attn_drop=None) -> Tensor:
     """VisionTransformer.forward, vit.py:335-351.  `drop` = (p, keep(site, shape)): training-mode dropout with given masks
-    (site -1: the encoder input [B, S, D], vit.py:175; the blocks' sites: encoder_block)."""
+    (site -1: the encoder input [B, S, D], vit.py:175; the blocks' sites: encoder_block); `attn_drop` = (p, keep): dropout on the attention
+    weights of every block (attention_dropout, vit.py:108), keep(-(2 + layer), (B, H, S, S))."""
     Q = _Q(emulate_bf16)
     w = sd["conv_proj.weight"]
     D = w.shape[0]
@@ -121,7 +128,7 @@ def vit_forward(sd: Dict[str, Tensor], img: Tensor, *, patch_size: int, num_head
         capture["embed"] = x.detach().clone()
     i = 0
     while f"encoder.layers.encoder_layer_{i}.ln_1.weight" in sd:
-        x = encoder_block(x, sd, f"encoder.layers.encoder_layer_{i}.", num_heads, robust, Q, eps, capture, f"layer{i}", drop, i)
+        x = encoder_block(x, sd, f"encoder.layers.encoder_layer_{i}.", num_heads, robust, Q, eps, capture, f"layer{i}", drop, i, attn_drop)
         if capture is not None:
             capture[f"layer{i}.out"] = x.detach().clone()
         i += 1

@@ -117,6 +117,30 @@ def test_vit_oracle_dropout_sites_match_the_torch_module_tree():
     assert (w - m.blocks[0]["fc1"].weight.grad).abs().max() < 1e-5 * w.abs().max() + 1e-7
 
 
+def test_vit_oracle_attention_dropout_is_dropout_of_the_attention_weights():
+    """attention_dropout (vit.py:108 -> nn.MultiheadAttention(dropout=p)): torch's module draws its own mask, so the oracle's site is
+    pinned against the definition written out -- out_proj(concat_h((softmax(q k^T / sqrt(dh)) * keep / (1 - p)) v))."""
+    torch.manual_seed(0)
+    B, S, E, H = 2, 5, 24, 3
+    x = torch.randn(B, S, E)
+    in_w, in_b = torch.randn(3 * E, E) * 0.2, torch.randn(3 * E) * 0.1
+    out_w, out_b = torch.randn(E, E) * 0.2, torch.randn(E) * 0.1
+    p = 0.3
+    keep = (torch.rand(B, H, S, S) >= p).to(torch.uint8)
+    got = V.mha_self_attention(x, in_w, in_b, out_w, out_b, H, False, V._Q(False), (p, keep))
+    q, k, v = (x @ in_w.t() + in_b).chunk(3, dim=-1)
+    sp = lambda t: t.reshape(B, S, H, E // H).transpose(1, 2)
+    a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / (E // H) ** 0.5, dim=-1) * keep / (1 - p)
+    ref = (a @ sp(v)).transpose(1, 2).reshape(B, S, E) @ out_w.t() + out_b
+    assert (got - ref).abs().max() < 1e-5
+    m = nn.MultiheadAttention(E, H, batch_first=True).eval()          # and with keep = 1 it is torch's module
+    with torch.no_grad():
+        m.in_proj_weight.copy_(in_w); m.in_proj_bias.copy_(in_b); m.out_proj.weight.copy_(out_w); m.out_proj.bias.copy_(out_b)
+    ones = torch.ones(B, H, S, S, dtype=torch.uint8)
+    full = V.mha_self_attention(x, in_w, in_b, out_w, out_b, H, False, V._Q(False), (0.0, ones))
+    assert (full - m(x, x, x, need_weights=False)[0]).abs().max() < 1e-5
+
+
 def test_patchify_cp1p2_is_conv2d():
     g = torch.Generator().manual_seed(0)
     conv = nn.Conv2d(3, 8, 16, 16)
