@@ -152,7 +152,9 @@ class Transformer(nn.Module):
     def forward(self, x, attn_mask=None, memories=None):
         if attn_mask is not None or memories is not None:
             raise NotImplementedError("attention masks / memory tokens are outside the encoder hot path")
-        _no_dropout(self.p if self.training else 0.0)
+        # the one `dropout` of the reference's Transformer (learnable_memory_vit.py:90-96) sits at four places per layer: on the attention
+        # weights (:83, composed on the materialised matrix), behind to_out (:61), behind the GELU (:37) and behind the second Linear (:39)
+        self._meta.dropout = self._meta.attn_dropout = self.p if self.training else 0.0
         # a sink only receives gradients of a training step: under no_grad (evaluation) nothing is written anyway
         for_sink = self._meta.sink is not None
         flat = []
@@ -187,9 +189,12 @@ class ViT(nn.Module):
         self.transformer.attach_grad_sink(sink)
 
     def img_to_tokens(self, img):
-        _no_dropout(self.dropout.p if self.training else 0.0)
         lin = self.to_patch_embedding[1]
-        return PatchEmbedFn.apply(img, lin.weight, lin.bias, self.pos_embedding, self.cls_token, self.patch, PATCH_P1P2C, None)
+        x = PatchEmbedFn.apply(img, lin.weight, lin.bias, self.pos_embedding, self.cls_token, self.patch, PATCH_P1P2C, None)
+        if self.training and self.dropout.p > 0.0:                  # emb_dropout (learnable_memory_vit.py:147): site -1
+            from .vit import _input_dropout
+            x = _input_dropout(x, self.transformer._meta, self.dropout.p)
+        return x
 
     def forward(self, img):
         x = self.transformer(self.img_to_tokens(img))

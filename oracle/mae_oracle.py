@@ -20,7 +20,17 @@ from .simple_vit_oracle import _Q, _bf16, gelu_erf, layer_norm, patchify_p1p2c
 Tensor = torch.Tensor
 
 
-def lucid_attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int, Q: _Q) -> Tensor:
+def _drop(t: Tensor, drop, site: int, shape=None) -> Tensor:
+    """nn.Dropout in training mode with a GIVEN keep mask (learnable_memory_vit.py:37,39,54,61,83): t * keep / (1 - p); `drop` = (p, keep(site, shape))."""
+    if drop is None:
+        return t
+    p, keep = drop
+    shp = tuple(t.shape) if shape is None else shape
+    return t * (keep(site, shp).reshape(t.shape).to(t.dtype) * (1.0 / (1.0 - p)))
+
+
+def lucid_attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int, Q: _Q, drop=None, layer: int = 0) -> Tensor:
+    """Dropout sites of layer i as in vit_oracle.encoder_block: -(2 + i) the attention weights [B,H,N,N] (:83), 3 i the to_out dropout (:61)."""
     B, N, _ = x.shape
     xn = Q(layer_norm(x, sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], 1e-5))
     q = Q(xn @ Q(sd[pfx + "to_q.weight"]).t())
@@ -33,22 +43,29 @@ def lucid_attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_
         p = torch.exp(dots - m)
         o = torch.matmul(_bf16(p), v) / p.sum(dim=-1, keepdim=True)
     else:
-        o = torch.matmul(torch.softmax(dots, dim=-1), v)
+        assert drop is None or not Q.emulate
+        o = torch.matmul(_drop(torch.softmax(dots, dim=-1), drop, -(2 + layer)), v)
     o = Q(o.permute(0, 2, 1, 3).reshape(B, N, heads * dim_head))
-    return o @ Q(sd[pfx + "to_out.0.weight"]).t() + sd[pfx + "to_out.0.bias"]
+    y = o @ Q(sd[pfx + "to_out.0.weight"]).t() + sd[pfx + "to_out.0.bias"]
+    return _drop(y, drop, 3 * layer, (B * N, y.shape[-1]))
 
 
-def lucid_feed_forward(x: Tensor, sd: Dict[str, Tensor], pfx: str, Q: _Q) -> Tensor:
+def lucid_feed_forward(x: Tensor, sd: Dict[str, Tensor], pfx: str, Q: _Q, drop=None, layer: int = 0) -> Tensor:
+    """Dropout sites 3 i + 1 behind the GELU (:37) and 3 i + 2 behind the second Linear (:39)."""
+    B, N, _ = x.shape
     xn = Q(layer_norm(x, sd[pfx + "net.0.weight"], sd[pfx + "net.0.bias"], 1e-5))
     h = Q(gelu_erf(xn @ Q(sd[pfx + "net.1.weight"]).t() + sd[pfx + "net.1.bias"]))
-    return h @ Q(sd[pfx + "net.4.weight"]).t() + sd[pfx + "net.4.bias"]
+    h = _drop(h, drop, 3 * layer + 1, (B * N, h.shape[-1]))
+    y = h @ Q(sd[pfx + "net.4.weight"]).t() + sd[pfx + "net.4.bias"]
+    return _drop(y, drop, 3 * layer + 2, (B * N, y.shape[-1]))
 
 
-def lucid_transformer(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int, Q: _Q) -> Tensor:
+def lucid_transformer(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int, Q: _Q, drop=None) -> Tensor:
+    """`drop` = (p, keep(site, shape)): the one `dropout` of learnable_memory_vit.Transformer (:90-96) at its four sites per layer."""
     i = 0
     while f"{pfx}layers.{i}.0.norm.weight" in sd:
-        x = lucid_attention(x, sd, f"{pfx}layers.{i}.0.", heads, dim_head, Q) + x
-        x = lucid_feed_forward(x, sd, f"{pfx}layers.{i}.1.", Q) + x
+        x = lucid_attention(x, sd, f"{pfx}layers.{i}.0.", heads, dim_head, Q, drop, i) + x
+        x = lucid_feed_forward(x, sd, f"{pfx}layers.{i}.1.", Q, drop, i) + x
         i += 1
     return x
 

@@ -828,6 +828,46 @@ def test_mae_vit_b_geometry_49_tokens_against_oracle(dev):
     print("worst grad rel-L2:", worst)
 
 
+def test_lucid_vit_dropout_against_oracle_with_injected_masks(dev):
+    """lucidrains-style ViT (the MAE encoder family) with `dropout` and `emb_dropout` > 0 (learnable_memory_vit.py:37,39,54,61,83,126,142):
+    the one dropout probability at its four sites per layer -- attention weights (composed path), to_out, GELU output, second Linear --
+    plus the embedding dropout; same keep masks in the oracle's restatement: logits and every gradient."""
+    from noise_robust_vit_amd.lucid_vit import ViT
+    from oracle import mae_oracle as MO
+    from oracle.simple_vit_oracle import layer_norm, patchify_p1p2c, _Q
+    torch.manual_seed(0)
+    cfg = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256)
+    model = ViT(dropout=0.15, emb_dropout=0.1, **cfg)
+    with torch.no_grad():
+        model.pos_embedding.mul_(0.02); model.cls_token.mul_(0.02)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    keep, ekeep = _keep_family(31, 0.15), _keep_family(32, 0.1)
+    model = model.to(dev).train()
+    model.transformer._meta.mask_source = lambda site, shape: (ekeep if site == -1 else keep)(site, shape)
+    logits = model(x.to(dev))
+    logits.square().mean().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+    def oracle(drop, edrop):
+        t = patchify_p1p2c(x, 16, 16) @ leaves["to_patch_embedding.1.weight"].t() + leaves["to_patch_embedding.1.bias"]
+        t = torch.cat([leaves["cls_token"].expand(4, -1, -1), t], dim=1) + leaves["pos_embedding"]
+        t = MO._drop(t, edrop, -1)
+        t = MO.lucid_transformer(t, leaves, "transformer.", 2, 64, _Q(False), drop)
+        h = layer_norm(t[:, 0], leaves["mlp_head.0.weight"], leaves["mlp_head.0.bias"], 1e-5)
+        return h @ leaves["mlp_head.1.weight"].t() + leaves["mlp_head.1.bias"]
+
+    ref = oracle((0.15, keep), (0.1, ekeep))
+    ref.square().mean().backward()
+    with torch.no_grad():
+        plain = oracle(None, None)
+    e = relmax(logits, ref)
+    print(f"lucid ViT dropout: logits vs fp32 oracle (same masks) {e:.3e}; the masks move the logits by {relmax(ref, plain):.2e}")
+    assert e < 1.2e-2 and relmax(ref, plain) > 10 * e
+    check_grads(model, {k: v.grad for k, v in leaves.items()}, tol=2.0e-2)
+
+
 def test_mae_gradients_through_the_reducer_sink_match_autograd(dev):
     """With a GradReducer attached (every training step: train.Trainer builds one even on a single GPU) both MAE transformers
     write their weight gradients into the flat buffer directly -- the fused [to_q; to_kv] projection as one TN GEMM per
