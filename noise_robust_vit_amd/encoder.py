@@ -136,6 +136,9 @@ class BlockMeta:
     mask_source: Optional[object] = None
     # dropout on the attention weights (vit.py:108): composed on the materialised [B,H,N,N] matrix (kernels.attn_dropout_fwd), site -(2 + i)
     attn_dropout: float = 0.0
+    # additive score bias of ONE call (attention / key-padding masks of the stand-alone MultiheadAttention, utils.py:741-751): fp32,
+    # broadcastable to [B, H, N, N], -inf = masked; composed path
+    attn_bias: Optional[Tensor] = None
 
 
 def _grad_target(meta: BlockMeta, p: Optional[Tensor]):
@@ -341,10 +344,12 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
     qkv = K.gemm_nt(xn, wqkv_b, out_dtype=torch.bfloat16,
                     epilogue=EPI_BIAS if bqkv is not None else EPI_NONE, bias=bqkv)
     scale = dh ** -0.5
-    if adrop is not None:                         # dropout on the attention weights: the composed path (materialised matrix), softmax or Sinkhorn
-        pscale, asite, pa = adrop
-        akeep = draw_keep(meta, asite, (B, H, N, N), x.device, p=pa)
-        o, asaved = K.attn_dropout_fwd(qkv, B, N, H, dh, scale, meta.robust, akeep, pscale)
+    if adrop is not None or meta.attn_bias is not None:      # weight dropout / score masks: the composed path (materialised matrix), softmax or Sinkhorn
+        pscale, akeep = 1.0, None
+        if adrop is not None:
+            pscale, asite, pa = adrop
+            akeep = draw_keep(meta, asite, (B, H, N, N), x.device, p=pa)
+        o, asaved = K.attn_dropout_fwd(qkv, B, N, H, dh, scale, meta.robust, akeep, pscale, bias=meta.attn_bias)
         aux = ("attn_dropout", asaved)
     elif meta.robust:                             # robust=True: softmax + Sinkhorn normalisation (utils.py:1025-1037), fused
         p7 = {}                                   # the composed path (N > 256 / dh != 64) hands its P7 to the backward through it
@@ -352,7 +357,7 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
         aux = (lse, scal, p7)
     else:
         o, aux = K.attn_fwd(qkv, B, N, H, dh, scale)
-    if _RECORDING is not None and adrop is None:
+    if _RECORDING is not None and adrop is None and meta.attn_bias is None:
         _record(qkv, aux, B, N, H, dh, scale, meta.robust)
     keep = None
     if residual and drop is not None:

@@ -568,29 +568,35 @@ def mask_mul_f32(a: Tensor, keep: Tensor, scale: float, out: Optional[Tensor] = 
     return o
 
 
-def attn_dropout_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float, robust: bool, keep: Tensor, pscale: float):
-    """Attention with dropout ON THE ATTENTION WEIGHTS (attention_dropout > 0: vit.py:108, torch's MultiheadAttention semantics):
-    composed on the materialised matrix like the robust attention beyond the fused shapes -- scores, softmax (the Sinkhorn op with
+def attn_dropout_fwd(qkv: Tensor, B: int, N: int, H: int, dh: int, scale: float, robust: bool, keep: Optional[Tensor], pscale: float,
+                     bias: Optional[Tensor] = None):
+    """Attention with what the fused kernels do not take, composed on the materialised matrix like the robust attention beyond the
+    fused shapes: an additive score bias (attention / key-padding masks of torch's MultiheadAttention: utils.py:741-751; -inf = masked)
+    and / or dropout ON THE ATTENTION WEIGHTS (attention_dropout > 0: vit.py:108) -- scores (+ bias), softmax (the Sinkhorn op with
     0 iterations) or the Sinkhorn normalisation (robust), the keep mask [B,H,N,N], P v.  Returns (out bf16, saved) with what the
-    backward needs (the dropped matrix, the statistics)."""
+    backward needs (the matrix that met v, the statistics)."""
     _bf16(qkv, "qkv")
     W = 3 * H * dh
     rs, cs, bs, hs = _head_strides(H, dh, W, N)
     iters = 3 if robust else 0
     S = _sinkhorn_scores(qkv, B, N, H, dh, scale)
+    if bias is not None:
+        _f32(bias, "bias")
+        S += bias                                   # broadcast over batch / heads: plumbing, once per call (not a BASELINE path)
     P, lse, avec, bvec = sinkhorn_fwd(S, iters=iters)
     del S
-    if tuple(keep.shape) != (B, H, N, N):
-        raise NrvError(f"attn_dropout_fwd: keep must be a uint8 mask of shape {(B, H, N, N)}")
-    mask_mul_f32(P, keep, pscale, out=P)
+    if keep is not None:
+        if tuple(keep.shape) != (B, H, N, N):
+            raise NrvError(f"attn_dropout_fwd: keep must be a uint8 mask of shape {(B, H, N, N)}")
+        mask_mul_f32(P, keep, pscale, out=P)
     out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=qkv.device)
     ors, ocs, obs, ohs = _head_strides(H, dh, H * dh, N)
     bgemm((P, 0), (N, 1, H * N * N, N * N), (qkv, 2 * H * dh), (rs, cs, bs, hs), (out, 0), (ors, ocs, obs, ohs), B, H, N, dh, N, 1.0)
-    return out, (P, lse, avec, bvec, keep, pscale, iters)
+    return out, (P, lse, avec, bvec, keep, pscale, iters, bias)
 
 
 def attn_dropout_bwd(qkv: Tensor, dout: Tensor, saved, B: int, N: int, H: int, dh: int, scale: float) -> Tensor:
-    Pd, lse, avec, bvec, keep, pscale, iters = saved
+    Pd, lse, avec, bvec, keep, pscale, iters, bias = saved
     W = 3 * H * dh
     rs, cs, bs, hs = _head_strides(H, dh, W, N)
     ors, ocs, obs, ohs = _head_strides(H, dh, H * dh, N)
@@ -599,8 +605,11 @@ def attn_dropout_bwd(qkv: Tensor, dout: Tensor, saved, B: int, N: int, H: int, d
     bgemm((Pd, 0), matT, (dout, 0), (ors, ocs, obs, ohs), (dqkv, 2 * H * dh), (rs, cs, bs, hs), B, H, N, dh, N, 1.0)          # dV = Pd^T dO
     dP = torch.empty_like(Pd)
     bgemm((dout, 0), (ors, ocs, obs, ohs), (qkv, 2 * H * dh), (cs, rs, bs, hs), (dP, 0), mat, B, H, N, N, dh, 1.0)           # d(Pd) = dO v^T
-    mask_mul_f32(dP, keep, pscale, out=dP)                                                                                      # dP
+    if keep is not None:
+        mask_mul_f32(dP, keep, pscale, out=dP)                                                                                  # dP
     S = _sinkhorn_scores(qkv, B, N, H, dh, scale)
+    if bias is not None:
+        S += bias                                   # masked scores are -inf: P0 = 0 there, and so is dS
     dS = sinkhorn_bwd(S, dP, lse, avec, bvec, iters=iters)
     del dP, S
     bgemm((dS, 0), mat, (qkv, H * dh), (rs, cs, bs, hs), (dqkv, 0), (rs, cs, bs, hs), B, H, N, dh, N, scale)

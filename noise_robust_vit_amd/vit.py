@@ -44,7 +44,7 @@ class MultiheadAttention(nn.Module):
 
     `forward(x, x, x, need_weights=False)` runs fused self-attention and returns `(out, None)` like the
     reference's call site expects (vit.py:124); `need_weights=True` also returns the attention weights (recomputed, no
-    gradient).  Only the self-attention form used by `EncoderBlock` exists (no masks, dropout p = 0).
+    gradient).  Only the self-attention form used by `EncoderBlock` exists; masks and attention dropout run on the composed path.
     """
 
     def __init__(self, embed_dim, num_heads, dropout=0.0, bias=True, add_bias_kv=False, add_zero_attn=False,
@@ -68,23 +68,52 @@ class MultiheadAttention(nn.Module):
     def attn_params(self):
         return [self.in_proj_weight, self.in_proj_bias, self.out_proj.weight, self.out_proj.bias]
 
+    def _score_bias(self, x, attn_mask, key_padding_mask):
+        """torch's mask semantics (utils.py:741-751 -> F.multi_head_attention_forward) as ONE additive fp32 bias broadcastable to
+        [B, H, N, N]: `attn_mask` [N, N] or [B * H, N, N], bool (True = not allowed) or float (added to the scores);
+        `key_padding_mask` [B, N], bool (True = ignore that key) or float.  None when no mask is given (the fused kernels run)."""
+        if attn_mask is None and key_padding_mask is None:
+            return None
+        B, N = x.shape[0], x.shape[1]
+        H = self.num_heads
+        bias = torch.zeros(B, H, N, N, dtype=torch.float32, device=x.device)
+        for m, view in ((attn_mask, None), (key_padding_mask, "keys")):
+            if m is None:
+                continue
+            m = m.to(x.device)
+            add = torch.zeros(m.shape, dtype=torch.float32, device=x.device).masked_fill_(m, float("-inf")) if m.dtype == torch.bool else m.to(torch.float32)
+            if view == "keys":
+                if tuple(add.shape) != (B, N):
+                    raise ValueError(f"key_padding_mask must be [{B}, {N}], got {tuple(add.shape)}")
+                bias += add[:, None, None, :]
+            elif add.dim() == 2:
+                if tuple(add.shape) != (N, N):
+                    raise ValueError(f"attn_mask must be [{N}, {N}] or [{B * H}, {N}, {N}], got {tuple(add.shape)}")
+                bias += add
+            else:
+                if tuple(add.shape) != (B * H, N, N):
+                    raise ValueError(f"attn_mask must be [{N}, {N}] or [{B * H}, {N}, {N}], got {tuple(add.shape)}")
+                bias += add.reshape(B, H, N, N)
+        return bias
+
     def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=False, attn_mask=None, **kw):
         """Self-attention `forward(x, x, x, need_weights=False) -> (out, None)` (utils.py:741-751,594-597; the call site is
         vit.py:124): packed QKV projection + bias -> fused softmax (or Sinkhorn, robust=True) attention -> out_proj + bias,
         all in libnrv_hip.so.  `batch_first=False` takes / returns [S, B, E] like torch's module."""
         if (key is not None and key is not query) or (value is not None and value is not query):
             raise NotImplementedError("self-attention only (query is key is value), as EncoderBlock calls it")
-        if key_padding_mask is not None or attn_mask is not None:
-            raise NotImplementedError("attention masks are outside the encoder hot path")
         x = query if self.batch_first else query.transpose(0, 1)
         meta = BlockMeta(heads=self.num_heads, dim_head=self.head_dim, eps=0.0, robust=bool(self.robust),
-                         attn_dropout=self.dropout if self.training else 0.0, mask_source=getattr(self, "mask_source", None))
+                         attn_dropout=self.dropout if self.training else 0.0, mask_source=getattr(self, "mask_source", None),
+                         attn_bias=self._score_bias(x, attn_mask, key_padding_mask))
         if not need_weights:
             out = AttnHalfFn.apply(x, meta, None, None, *self.attn_params())
             return (out if self.batch_first else out.transpose(0, 1)), None
         # need_weights=True (utils.py:741-751, 594-597): the fused kernels never materialise the weights, so they are recomputed from
         # q, k and the saved statistics (nrv_attn_probs; the Sinkhorn-scaled matrix for robust=True) -- [B, N, N] averaged over the
         # heads as torch's module returns them by default, [B, H, N, N] with average_attn_weights=False; introspection: no gradient
+        if meta.attn_bias is not None or meta.attn_dropout > 0.0:
+            raise NotImplementedError("need_weights=True together with masks or attention dropout")
         from .encoder import record_attention
         maps: list = []
         with record_attention(maps):

@@ -681,8 +681,11 @@ def test_multihead_attention_forward_matches_torch_module(dev, batch_first):
     assert torch.equal(out2, out.detach())
     assert w_avg.shape == rw_avg.shape == (B, S, S) and w_all.shape == rw_all.shape == (B, H, S, S)
     assert (w_avg.cpu() - rw_avg).abs().max().item() < 5e-3 and (w_all.cpu() - rw_all).abs().max().item() < 5e-3
-    with pytest.raises(NotImplementedError):
-        mine(xd, xd, xd, attn_mask=torch.zeros(S, S, device=dev))
+    with pytest.raises(NotImplementedError):                 # the weights of a masked call are not recomputed (composed path)
+        mine(xd, xd, xd, attn_mask=torch.zeros(S, S, device=dev), need_weights=True)
+    with torch.no_grad():                                    # a zero additive mask is the unmasked attention, on the composed path
+        out3, _ = mine(xd, xd, xd, attn_mask=torch.zeros(S, S, device=dev))
+    assert relmax(out3, out.detach()) < 1.2e-2
 
 
 def test_state_dict_roundtrip_and_legacy_mlp_keys(dev):
@@ -826,6 +829,43 @@ def test_mae_vit_b_geometry_49_tokens_against_oracle(dev):
         worst = max(worst, (rel, k))
         assert rel < 1.8e-2, (k, rel)                    # measured worst 8.7e-3
     print("worst grad rel-L2:", worst)
+
+
+@pytest.mark.parametrize("kind", ["causal_bool", "float_per_head", "key_padding", "both"])
+def test_multihead_attention_masks_against_torch_module(dev, kind):
+    """`attn_mask` / `key_padding_mask` of the stand-alone MultiheadAttention (utils.py:741-751: the forked torch module's forward
+    signature) on the composed path, against torch.nn.MultiheadAttention itself (CPU fp32) with the same weights: output and the
+    gradients of the input and of every parameter."""
+    from noise_robust_vit_amd.vit import MultiheadAttention
+    torch.manual_seed(0)
+    B, N, E, H = 3, 10, 64, 2
+    ref = torch.nn.MultiheadAttention(E, H, batch_first=True)
+    with torch.no_grad():
+        ref.in_proj_bias.normal_(std=0.1); ref.out_proj.bias.normal_(std=0.1)
+    ours = MultiheadAttention(E, H, batch_first=True)
+    ours.load_state_dict(ref.state_dict())
+    ours = ours.to(dev)
+    x = torch.randn(B, N, E)
+    am = kp = None
+    if kind in ("causal_bool", "both"):
+        am = torch.triu(torch.ones(N, N, dtype=torch.bool), diagonal=1)
+    if kind == "float_per_head":
+        am = torch.randn(B * H, N, N) * 0.5
+    if kind in ("key_padding", "both"):
+        kp = torch.zeros(B, N, dtype=torch.bool); kp[0, 7:] = True; kp[2, 9:] = True
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr, xr, xr, attn_mask=am, key_padding_mask=kp, need_weights=False)
+    w = torch.randn(B, N, E)
+    (yr * w).sum().backward()
+    xo = x.to(dev).requires_grad_(True)
+    yo, none = ours(xo, xo, xo, attn_mask=am, key_padding_mask=kp, need_weights=False)
+    assert none is None
+    (yo * w.to(dev)).sum().backward()
+    assert relmax(yo, yr) < 1.2e-2, relmax(yo, yr)
+    assert ((xo.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item() < 2e-2
+    for (k, po), (_, pr) in zip(ours.named_parameters(), ref.named_parameters()):
+        rel = ((po.grad.cpu() - pr.grad).norm() / pr.grad.norm().clamp_min(1e-30)).item()
+        assert rel < 2e-2, (k, rel)
 
 
 def test_lucid_vit_dropout_against_oracle_with_injected_masks(dev):
