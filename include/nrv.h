@@ -29,11 +29,12 @@
 extern "C" {
 #endif
 
-#define NRV_ABI_VERSION 12
+#define NRV_ABI_VERSION 13
 
 /* dtype codes */
 #define NRV_F32 0
 #define NRV_BF16 1
+#define NRV_U8 2                 /* the 8-bit gelu' stream of NRV_EPI_BIAS_GELU_Q8 / NRV_EPI_DGELU_Q8 only */
 
 /* error codes */
 #define NRV_OK 0
@@ -50,6 +51,8 @@ extern "C" {
 #define NRV_EPI_BIAS_GELU 2      /* u = acc + bias[n]; aux_out = bf16(gelu_erf'(u)) (optional); C = gelu_erf(u) */
 #define NRV_EPI_BIAS_RESIDUAL 3  /* C = acc + bias[n] (bias optional) + aux[m % aux_row_mod][n] */
 #define NRV_EPI_DGELU 4          /* C = acc * aux[m][n]     (aux = the bf16 gelu' saved by NRV_EPI_BIAS_GELU) */
+#define NRV_EPI_BIAS_GELU_Q8 5   /* NRV_EPI_BIAS_GELU with aux_out as bytes: q = round(202 gelu_erf'(u)) + 26  (bf16 C only)      */
+#define NRV_EPI_DGELU_Q8 6       /* C = acc * (aux[m][n] - 26) / 202   (aux = the NRV_U8 stream saved by NRV_EPI_BIAS_GELU_Q8; bf16 C) */
 
 int nrv_abi_version(void);
 const char* nrv_error_string(int code);
@@ -90,6 +93,8 @@ int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const flo
  *        simple_vit.py:142-143); 0 means row m.
  *   aux_out: optional bf16 [M,N] (ldc_aux) receiving gelu'(pre-activation) for NRV_EPI_BIAS_GELU: the backward's
  *        NRV_EPI_DGELU epilogue is then one multiply, no second erf/exp evaluation.
+ *        The _Q8 pair keeps the same stream in one byte per element (gelu_erf' lies in [-0.129, 1.129]; step 1/202, i.e. an
+ *        absolute error <= 0.0025 -- what bf16 leaves on values in [0.5, 1)): ld_aux_out % 16 == 0, aux_dtype = NRV_U8 on the way back.
  *   Output row remap (class-token slot, vit.py:341-342): if out_group > 0 the result row m is
  *   stored at row (m / out_group) * out_group_stride + (m % out_group) + out_row_offset of C
  *   (and of aux, when aux_row_mod == 0).  The remap and aux_row_mod ride on NRV_EPI_BIAS_RESIDUAL (the patch

@@ -15,10 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _DEFAULT_LIB = os.path.join(_HERE, "lib", "libnrv_hip.so")
 LIB_PATH = _DEFAULT_LIB       # no environment override: what runs is the in-tree library (tools/_devlib.py swaps it for A/B runs)
 
-NRV_F32, NRV_BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4
+NRV_F32, NRV_BF16, NRV_U8 = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU_Q8, EPI_DGELU_Q8 = 0, 1, 2, 3, 4, 5, 6
 PATCH_P1P2C, PATCH_CP1P2 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 ATTN_QKV_BLOCKED, ATTN_OUT_BLOCKED = 1, 2      # include/nrv.h: NRV_ATTN_*_BLOCKED
 
 

@@ -135,6 +135,33 @@ __device__ __forceinline__ void store_b64_row(rawx2_t v, __amdgpu_buffer_rsrc_t 
     asm volatile("s_nop 1" :: "v"(v) : "memory");
 }
 
+// the 8-bit gelu' stream (NRV_EPI_BIAS_GELU_Q8 writes it, NRV_EPI_DGELU_Q8 reads it): gelu_erf' lies in [-0.1290, 1.1290]; a byte q stands for
+// (q - 26) / 202 (step 0.00495: the rounding error <= 0.0025 is what bf16 leaves on values in [0.5, 1)); half the bytes of the bf16 stream
+// in the two HBM-bound epilogues of a layer (fc1: 620 -> 465 MB written, dU: 392 -> 237 MB read at ViT-B/16 batch 256)
+constexpr bool epi_gelu(int e) { return e == NRV_EPI_BIAS_GELU || e == NRV_EPI_BIAS_GELU_Q8; }
+constexpr bool epi_dgelu(int e) { return e == NRV_EPI_DGELU || e == NRV_EPI_DGELU_Q8; }
+constexpr bool epi_q8(int e) { return e == NRV_EPI_BIAS_GELU_Q8 || e == NRV_EPI_DGELU_Q8; }
+#define NRV_Q8_SCALE 202.0f
+#define NRV_Q8_ZERO 26.0f
+
+// four gelu' values -> four bytes (v_cvt_pk_u8_f32 rounds to nearest, measured: tests/test_kernels_gpu.py)
+__device__ __forceinline__ unsigned q8_pack4(f32x4_t g) {
+    unsigned r = 0;
+    const float y0 = fmaf(g[0], NRV_Q8_SCALE, NRV_Q8_ZERO), y1 = fmaf(g[1], NRV_Q8_SCALE, NRV_Q8_ZERO);
+    const float y2 = fmaf(g[2], NRV_Q8_SCALE, NRV_Q8_ZERO), y3 = fmaf(g[3], NRV_Q8_SCALE, NRV_Q8_ZERO);
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, %0\n\tv_cvt_pk_u8_f32 %0, %2, 1, %0\n\tv_cvt_pk_u8_f32 %0, %3, 2, %0\n\tv_cvt_pk_u8_f32 %0, %4, 3, %0"
+        : "+v"(r) : "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+    return r;
+}
+// four bytes -> four gelu' values
+__device__ __forceinline__ f32x4_t q8_unpack4(unsigned d) {
+    float q0, q1, q2, q3;
+    asm("v_cvt_f32_ubyte0 %0, %4\n\tv_cvt_f32_ubyte1 %1, %4\n\tv_cvt_f32_ubyte2 %2, %4\n\tv_cvt_f32_ubyte3 %3, %4"
+        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(d));
+    constexpr float c = 1.0f / NRV_Q8_SCALE, z = -NRV_Q8_ZERO / NRV_Q8_SCALE;
+    return f32x4_t{fmaf(q0, c, z), fmaf(q1, c, z), fmaf(q2, c, z), fmaf(q3, c, z)};
+}
+
 template <int EPI, bool OUT_F32, bool AUX_F32, int MI>
 __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /* the wave's 4-KiB LDS patch */, const EpiParams& e,
                                              int row_base /* global row of the wave's block (wave-uniform) */,
@@ -154,9 +181,11 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
     const bool col_ok = rcol * CW < cols_left;          // N % 8 == 0: a chunk is entirely inside or outside
     const int rows_here = rows_left < MI * 16 ? rows_left : MI * 16;
     const int cols_here = cols_left < 64 ? cols_left : 64;
-    constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
+    constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || epi_dgelu(EPI);
+    constexpr bool Q8 = epi_q8(EPI);                    // the gelu' stream as bytes (bf16 C only)
+    static_assert(!Q8 || !OUT_F32, "the 8-bit gelu' stream goes with bf16 outputs: 8 columns = 8 bytes per lane");
     constexpr bool AUX32 = EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32;
-    constexpr int ES = OUT_F32 ? 4 : 2, AS = AUX32 ? 4 : 2;
+    constexpr int ES = OUT_F32 ? 4 : 2, AS = AUX32 ? 4 : (Q8 ? 1 : 2), US = Q8 ? 1 : 2;
     constexpr int AW = CW * AS / 4;                     // dwords of the epilogue operand per lane and pass: 2, 4 or 8
     constexpr int HALF = MI > 8 ? (MI + 3) / 4 : (MI + 1) / 2;      // operand-prefetch depth, bounded by the register file
 
@@ -173,17 +202,17 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(HAS_AUX ? static_cast<const char*>(e.aux) + ((long long)row_base * e.ld_aux + col_base) * AS : nullptr,
                                                 HAS_AUX ? ((unsigned long long)(rows_here - 1) * e.ld_aux + cols_here) * AS : 0ull);
     const unsigned a_vo = (HAS_AUX && col_ok) ? (unsigned)(rrow * a_rs + rcol * CW * AS) : NRV_OOB;
-    const bool want_u = EPI == NRV_EPI_BIAS_GELU && e.aux_out != nullptr;
-    int u_rs = want_u ? (int)e.ld_aux_out * 2 : 0;
+    const bool want_u = epi_gelu(EPI) && e.aux_out != nullptr;
+    int u_rs = want_u ? (int)e.ld_aux_out * US : 0;
     asm volatile("" : "+s"(u_rs));
-    const __amdgpu_buffer_rsrc_t ru = make_rsrc(want_u ? static_cast<char*>(e.aux_out) + ((long long)row_base * e.ld_aux_out + col_base) * 2 : nullptr,
-                                                want_u ? ((unsigned long long)(rows_here - 1) * e.ld_aux_out + cols_here) * 2 : 0ull);
-    const unsigned u_vo = (want_u && col_ok) ? (unsigned)(rrow * u_rs + rcol * CW * 2) : NRV_OOB;
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(want_u ? static_cast<char*>(e.aux_out) + ((long long)row_base * e.ld_aux_out + col_base) * US : nullptr,
+                                                want_u ? ((unsigned long long)(rows_here - 1) * e.ld_aux_out + cols_here) * US : 0ull);
+    const unsigned u_vo = (want_u && col_ok) ? (unsigned)(rrow * u_rs + rcol * CW * US) : NRV_OOB;
 
     f32x4_t bias4[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) bias4[v] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr bool HAS_BIAS = EPI == NRV_EPI_BIAS || EPI == NRV_EPI_BIAS_GELU || EPI == NRV_EPI_BIAS_RESIDUAL;
+    constexpr bool HAS_BIAS = EPI == NRV_EPI_BIAS || epi_gelu(EPI) || EPI == NRV_EPI_BIAS_RESIDUAL;
     const bool add_bias = HAS_BIAS && e.bias != nullptr;                 // uniform
     if (add_bias && col_ok) {
 #pragma unroll
@@ -204,7 +233,7 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
                         const int r0 = mi * 16 + RPI * i;                // first row of the pass (uniform)
                         const int so = (r0 < rows_here ? r0 : 0) * a_rs;  // keep soffset inside the records; the lanes are dropped below
                         const unsigned vo = r0 < rows_here ? a_vo : NRV_OOB;
-                        constexpr int LAUX = EPI == NRV_EPI_DGELU ? 2 : 0;      // the gelu' stream is read once: non-temporal
+                        constexpr int LAUX = epi_dgelu(EPI) ? 2 : 0;      // the gelu' stream is read once: non-temporal
                         if (AW == 2) {
                             const rawx2_t t = __builtin_amdgcn_raw_buffer_load_b64(ra, vo, so, LAUX);
                             auxr[mh][i][0] = t[0]; auxr[mh][i][1] = t[1];
@@ -240,18 +269,24 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
                         for (int v = 0; v < V; ++v) {
                             f32x4_t x = val[v];
                             if (HAS_BIAS) x += bias4[v];
-                            if (EPI == NRV_EPI_BIAS_GELU) {
+                            if (epi_gelu(EPI)) {
                                 // one erf/exp evaluation gives both gelu(u) (the output) and gelu'(u) (saved for the backward)
                                 f32x4_t dg;
                                 gelu_both4(x, x, dg);
-                                pku[2 * v] = pack_bf16x2(dg[0], dg[1]);
-                                pku[2 * v + 1] = pack_bf16x2(dg[2], dg[3]);
+                                if (Q8) {
+                                    pku[v] = q8_pack4(dg);
+                                } else {
+                                    pku[2 * v] = pack_bf16x2(dg[0], dg[1]);
+                                    pku[2 * v + 1] = pack_bf16x2(dg[2], dg[3]);
+                                }
                             }
                             if (HAS_AUX) {
                                 f32x4_t a;
                                 if (AUX32) {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) a[j] = __uint_as_float(auxr[mh][i][4 * v + j]);
+                                } else if (Q8) {
+                                    a = q8_unpack4(auxr[mh][i][v]);
                                 } else {
                                     const unsigned a0 = auxr[mh][i][2 * v], a1 = auxr[mh][i][2 * v + 1];
                                     a = f32x4_t{bf16lo_to_f32(a0), bf16hi_to_f32(a0), bf16lo_to_f32(a1), bf16hi_to_f32(a1)};
@@ -270,8 +305,11 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
                             const rawx4_t o = {pk[0], pk[1], pk[2 * V - 2], pk[2 * V - 1]};
                             store_b128_row(o, rc, c_vo, r0 * c_rs);
                         }
-                        if (EPI == NRV_EPI_BIAS_GELU && want_u) {
-                            if (V == 2) {
+                        if (epi_gelu(EPI) && want_u) {
+                            if (Q8) {
+                                const rawx2_t o = {pku[0], pku[1]};
+                                store_b64_row<2>(o, ru, u_vo, r0 * u_rs);
+                            } else if (V == 2) {
                                 const rawx4_t o = {pku[0], pku[1], pku[2 * V - 2], pku[2 * V - 1]};
                                 store_b128_row<2>(o, ru, u_vo, r0 * u_rs);
                             } else {
@@ -584,9 +622,9 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 template <int EPI, bool OUT_F32, bool AUX_F32, int MI>
 constexpr int epilogue_vm_ops() {
     constexpr int CW = OUT_F32 ? 4 : 8, NIT = 16 / (64 / (64 / CW));
-    constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || EPI == NRV_EPI_DGELU;
-    constexpr int AS = (EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32) ? 4 : 2, AW = CW * AS / 4;
-    return MI * NIT * (1 + (EPI == NRV_EPI_BIAS_GELU ? 1 : 0) + (HAS_AUX ? (AW <= 4 ? 1 : AW / 4) : 0));
+    constexpr bool HAS_AUX = EPI == NRV_EPI_BIAS_RESIDUAL || epi_dgelu(EPI);
+    constexpr int AS = (EPI == NRV_EPI_BIAS_RESIDUAL && AUX_F32) ? 4 : (epi_q8(EPI) ? 1 : 2), AW = CW * AS / 4;
+    return MI * NIT * (1 + (epi_gelu(EPI) ? 1 : 0) + (HAS_AUX ? (AW <= 4 ? 1 : AW / 4) : 0));
 }
 
 template <typename C>
@@ -902,7 +940,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_nt8_kernel(const GemmNTPar
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));        // opaque per tile: the epilogue's per-lane offsets are recomputed here, not kept in registers through the K loops
             epilogue_lin<EPI, OUT_F32, AUX_F32, C::MI>(acc, reinterpret_cast<float*>(patch), p.e, row_base, col_base, lane_e);
-            count_stores = M - row_base >= C::MI * 16 && N - col_base >= 64 && (EPI != NRV_EPI_BIAS_GELU || p.e.aux_out != nullptr);
+            count_stores = M - row_base >= C::MI * 16 && N - col_base >= 64 && (!epi_gelu(EPI) || p.e.aux_out != nullptr);
         }
         NRV_TILE_STAMP();            // [4 + 4 i] epilogue issued
         if (!has_next) break;
@@ -1757,17 +1795,19 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     if ((out_group > 0 || aux_row_mod > 0) && epilogue_id != NRV_EPI_BIAS_RESIDUAL) return NRV_ERR_EPILOGUE;   // nrv.h: remap rides on that epilogue
     // the epilogue addresses a wave's block (<= 160 rows) with 32-bit byte offsets
     if (ldc * 4 * 320 >= 0x7fffffffll || ld_aux * 4 * 320 >= 0x7fffffffll || ld_aux_out * 2 * 320 >= 0x7fffffffll) return NRV_ERR_SHAPE;
-    const bool need_aux = epilogue_id == NRV_EPI_BIAS_RESIDUAL || epilogue_id == NRV_EPI_DGELU;
+    if (epi_q8(epilogue_id) && c_dtype != NRV_BF16) return NRV_ERR_DTYPE;                    // the byte stream goes with bf16 outputs
+    const bool need_aux = epilogue_id == NRV_EPI_BIAS_RESIDUAL || epi_dgelu(epilogue_id);
     if (need_aux) {
         if (!aux) return NRV_ERR_EPILOGUE;
-        if (aux_dtype != NRV_F32 && aux_dtype != NRV_BF16) return NRV_ERR_DTYPE;
+        if (aux_dtype != NRV_F32 && aux_dtype != NRV_BF16 && aux_dtype != NRV_U8) return NRV_ERR_DTYPE;
         if (epilogue_id == NRV_EPI_DGELU && aux_dtype != NRV_BF16) return NRV_ERR_DTYPE;
-        const int64_t asz = aux_dtype == NRV_F32 ? 4 : 2;
+        if ((epilogue_id == NRV_EPI_DGELU_Q8) != (aux_dtype == NRV_U8)) return NRV_ERR_DTYPE;
+        const int64_t asz = aux_dtype == NRV_F32 ? 4 : aux_dtype == NRV_U8 ? 1 : 2;
         if (ld_aux < N || ((ld_aux * asz) & 15) || !nrv_aligned16(aux)) return NRV_ERR_ALIGN;
     }
-    if ((epilogue_id == NRV_EPI_BIAS || epilogue_id == NRV_EPI_BIAS_GELU) && !bias) return NRV_ERR_EPILOGUE;
+    if ((epilogue_id == NRV_EPI_BIAS || epi_gelu(epilogue_id)) && !bias) return NRV_ERR_EPILOGUE;
     if (bias && !nrv_aligned16(bias)) return NRV_ERR_ALIGN;
-    if (aux_out && (ld_aux_out < N || (ld_aux_out & 7) || !nrv_aligned16(aux_out))) return NRV_ERR_ALIGN;
+    if (aux_out && (ld_aux_out < N || (ld_aux_out & (epilogue_id == NRV_EPI_BIAS_GELU_Q8 ? 15 : 7)) || !nrv_aligned16(aux_out))) return NRV_ERR_ALIGN;
 
     GemmNTParams p;
     p.A = static_cast<const bf16_t*>(A);
@@ -1794,6 +1834,10 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
             return af32 ? launch_nt<NRV_EPI_BIAS_RESIDUAL, false, true>(p, s) : launch_nt<NRV_EPI_BIAS_RESIDUAL, false, false>(p, s);
         case NRV_EPI_DGELU:
             return of32 ? launch_nt<NRV_EPI_DGELU, true, false>(p, s) : launch_nt<NRV_EPI_DGELU, false, false>(p, s);
+        case NRV_EPI_BIAS_GELU_Q8:
+            return launch_nt<NRV_EPI_BIAS_GELU_Q8, false, true>(p, s);
+        case NRV_EPI_DGELU_Q8:
+            return launch_nt<NRV_EPI_DGELU_Q8, false, false>(p, s);
         default:
             return NRV_ERR_EPILOGUE;
     }

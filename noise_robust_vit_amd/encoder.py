@@ -26,7 +26,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import kernels as K
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_NONE, NrvError)
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_Q8, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_DGELU_Q8, EPI_NONE, NrvError)
 
 Tensor = torch.Tensor
 
@@ -416,6 +416,9 @@ def attn_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, B: int,
 # ----------------------------------------------------------------------------------------------
 # MLP half
 # ----------------------------------------------------------------------------------------------
+GELU_STREAM_U8 = True        # False: the bf16 gelu' stream of rounds 1 - 3 (A/B, tests)
+
+
 def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residual: bool, save: bool = True, drop=None):
     """`save=False` (no gradient will be asked for): the fc1 epilogue skips the gelu'(u) output -- a 310 MB store stream per
     layer on ViT-B/16 at batch 256."""
@@ -423,8 +426,11 @@ def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residua
     w1_b, _ = WEIGHTS.get(w1, True)
     w2_b, _ = WEIGHTS.get(w2, True)
     T = x.shape[0]
-    u = torch.empty(T, w1.shape[0], dtype=torch.bfloat16, device=x.device) if save else None     # receives gelu'(pre-activation)
-    h = K.gemm_nt(xn, w1_b, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=b1, aux_out=u)
+    # gelu'(pre-activation) for the backward: one byte per element (include/nrv.h NRV_EPI_BIAS_GELU_Q8) unless a dropout mask is
+    # going to be multiplied into it (a scaled value leaves the byte code's range)
+    q8 = GELU_STREAM_U8 and drop is None and w1.shape[0] % 16 == 0
+    u = torch.empty(T, w1.shape[0], dtype=torch.uint8 if q8 else torch.bfloat16, device=x.device) if save else None
+    h = K.gemm_nt(xn, w1_b, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU_Q8 if q8 else EPI_BIAS_GELU, bias=b1, aux_out=u)
     keep2 = None
     if residual and drop is not None:
         # Dropout behind the GELU (vit.py:100) and behind the second Linear (vit.py:101).  The first mask is applied to the saved
@@ -456,7 +462,7 @@ def mlp_half_bwd(dy32: Optional[Tensor], dy16: Optional[Tensor], saved, meta: Bl
     _, w2_t = WEIGHTS.get(w2, True)
     _, w1_t = WEIGHTS.get(w1, True)
     dw2, db2 = _dw_db(meta, dy16, h, w2, b2)
-    du = K.gemm_nt(dy16, w2_t, out_dtype=torch.bfloat16, epilogue=EPI_DGELU, aux=u)
+    du = K.gemm_nt(dy16, w2_t, out_dtype=torch.bfloat16, epilogue=EPI_DGELU_Q8 if u.dtype == torch.uint8 else EPI_DGELU, aux=u)
     dw1, db1 = _dw_db(meta, du, xn, w1, b1)
     dxn = K.gemm_nt(du, w1_t, out_dtype=torch.bfloat16)
     tg, bg = _grad_target(meta, ln_w)

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_NONE, NRV_BF16, NRV_F32,
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_Q8, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_DGELU_Q8, EPI_NONE, NRV_BF16, NRV_F32, NRV_U8,
                    PATCH_CP1P2, PATCH_P1P2C, NrvError, check)
 
 Tensor = torch.Tensor
@@ -175,8 +175,12 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
         out = torch.empty(M, N, dtype=out_dtype, device=A.device)
     _, _, ldc = _rows2d(out, "out")
     ld_aux = 0
+    aux_code = 0
     if aux is not None:
         _dev(aux, "aux")
+        if (epilogue == EPI_DGELU_Q8) != (aux.dtype == torch.uint8):
+            raise NrvError("gemm_nt: the 8-bit gelu' stream (uint8) goes with EPI_DGELU_Q8 and with nothing else")
+        aux_code = NRV_U8 if aux.dtype == torch.uint8 else _dt(aux, "aux")
         arows, acols, ld_aux = _rows2d(aux, "aux")
         # the epilogue reads aux through raw pointers: row m % aux_row_mod, or the (remapped) output row
         need = aux_row_mod if aux_row_mod else (M if not out_group else (M - 1) // out_group * out_group_stride + (M - 1) % out_group + out_row_offset + 1)
@@ -190,7 +194,12 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
         raise NrvError(f"gemm_nt: out is {tuple(out.shape)}, result is [{M}, {N}]")
     ld_ao = 0
     if aux_out is not None:
-        _bf16(aux_out, "aux_out")
+        if epilogue == EPI_BIAS_GELU_Q8:
+            _dev(aux_out, "aux_out")
+            if aux_out.dtype != torch.uint8:
+                raise NrvError("gemm_nt: EPI_BIAS_GELU_Q8 writes the gelu' stream as uint8")
+        else:
+            _bf16(aux_out, "aux_out")
         _, _, ld_ao = _rows2d(aux_out, "aux_out")
     if bias is not None:
         _f32(bias, "bias")
@@ -199,11 +208,11 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
     if aux is not None and not aux_row_mod:
         nb += M * N * aux.element_size()
     if aux_out is not None:
-        nb += M * N * 2
+        nb += M * N * aux_out.element_size()
     _run("gemm_nt", 2.0 * M * N * K, nb,
          lambda: lib.nrv_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), _dt(out, "out"), ldc,
                                       M, N, K, int(epilogue), _ptr(bias),
-                                      _ptr(aux), _dt(aux, "aux") if aux is not None else 0, ld_aux, int(aux_row_mod),
+                                      _ptr(aux), aux_code, ld_aux, int(aux_row_mod),
                                       _ptr(aux_out), ld_ao, int(out_group), int(out_group_stride), int(out_row_offset),
                                       _stream()),
          "nrv_gemm_nt_bf16")

@@ -235,6 +235,43 @@ def test_gemm_nt_many_tiles(dev, M, N, K):
         assert out.reshape(M // G, G + 1, N)[:, 0].abs().max() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(50432, 3072, 768), (1000, 264, 136), (321, 72, 64), (2000, 1536, 384), (7, 8, 8)])
+def test_gemm_nt_gelu_stream_8bit(dev, M, N, K):
+    """NRV_EPI_BIAS_GELU_Q8 / NRV_EPI_DGELU_Q8 (include/nrv.h): the same GELU output as the bf16-stream epilogue, bit for bit; the
+    byte q stands for gelu'(u) = (q - 26) / 202 to half a step (0.0025) + the kernel's erf approximation; the backward epilogue
+    multiplies by exactly the decoded value; nothing is written outside the stream's [M, N] block."""
+    k = _k()
+    from noise_robust_vit_amd._lib import EPI_BIAS_GELU, EPI_BIAS_GELU_Q8, EPI_DGELU_Q8
+    A = rnd((M, K), dev, 26, 0.5)
+    B = rnd((N, K), dev, 27, 0.3)
+    bias = rnd((N,), dev, 28, 1.0, torch.float32)
+    h16 = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=bias)
+    PADR, ld = 3, (N + 31) // 16 * 16
+    qbig = torch.full((M + 2 * PADR, ld), 255, dtype=torch.uint8, device=dev)
+    q = qbig[PADR:PADR + M, :N]
+    h = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU_Q8, bias=bias, aux_out=q)
+    assert torch.equal(h, h16)
+    guard = qbig.clone()
+    guard[PADR:PADR + M, :N] = 255
+    assert (guard == 255).all(), "the 8-bit gelu' stream was written outside its block"
+    pre = (A.float() @ B.float().t() + bias).requires_grad_(True)
+    torch.nn.functional.gelu(pre).sum().backward()
+    g = (q.float() - 26.0) / 202.0
+    err = (g - pre.grad).abs().max().item()
+    assert err <= 0.5 / 202 + 3e-4, err
+    assert int(q.min()) >= 0 and int(q.max()) <= 254 and (M * N < 10000 or (int(q.min()) <= 1 and int(q.max()) >= 253))
+    del pre
+    dY = rnd((M, 2 * K), dev, 29, 0.5)
+    W = rnd((N, 2 * K), dev, 30, 0.2)
+    c = k.gemm_nt(dY, W, out_dtype=torch.bfloat16, epilogue=EPI_DGELU_Q8, aux=q)
+    ref = (dY.float() @ W.float().t()) * g
+    assert ((c.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-5 * math.sqrt(2 * K) * ref.abs().max()).all()
+    with pytest.raises(Exception):
+        k.gemm_nt(dY, W, out_dtype=torch.float32, epilogue=EPI_DGELU_Q8, aux=q)       # bf16 outputs only
+    with pytest.raises(Exception):
+        k.gemm_nt(dY, W, out_dtype=torch.bfloat16, epilogue=EPI_DGELU_Q8, aux=h)      # a bf16 stream with the byte epilogue
+
+
 @pytest.mark.parametrize("M,N,K", [(257, 104, 72), (300, 576, 192), (129, 264, 64), (1, 8, 8), (321, 72, 136), (1000, 768, 768)])
 def test_gemm_nt_edge_tiles_write_nothing_outside(dev, M, N, K):
     """The epilogue drops rows >= M and columns >= N through the buffer descriptor's range check (no per-lane address

@@ -32,6 +32,7 @@ def run(M, N, Kd, epi, odt, name):
     bias = torch.randn(N, device=dev); aux = None; aux_out = None
     if epi == EPI_BIAS_RESIDUAL: aux = torch.randn(M, N, device=dev)
     if epi == EPI_DGELU: aux = torch.randn(M, N, device=dev).bfloat16()
+    if epi == EPI_DGELU_Q8: aux = torch.randint(0, 255, (M, N), dtype=torch.uint8, device=dev)
     if epi == EPI_BIAS_GELU: aux_out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     out = torch.empty(M, N, dtype=odt, device=dev)
     f = lambda: K.gemm_nt(A, B, epilogue=epi, bias=bias if epi in (1, 2, 3) else None, aux=aux, aux_out=aux_out, out=out)
@@ -64,6 +65,7 @@ def run(M, N, Kd, epi, odt, name):
 
 for name, M, N, Kd, epi, odt in [("dO none", T, 768, 768, 0, torch.bfloat16), ("qkv bias", T, 2304, 768, 1, torch.bfloat16),
                                   ("oproj resid f32", T, 768, 768, 3, torch.float32), ("fc1 gelu", T, 3072, 768, 2, torch.bfloat16),
-                                  ("dU dgelu", T, 3072, 768, 4, torch.bfloat16),
+                                  ("dU dgelu", T, 3072, 768, 4, torch.bfloat16), ("dU dgelu 8-bit stream", T, 3072, 768, 6, torch.bfloat16),
+                                  ("dU shape, no epilogue", T, 3072, 768, 0, torch.bfloat16),
                                   ("dXn2 none K3072", T, 768, 3072, 0, torch.bfloat16), ("sq8192", 8192, 8192, 8192, 0, torch.bfloat16)]:
     run(M, N, Kd, epi, odt, name)

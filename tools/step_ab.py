@@ -3,6 +3,8 @@
 box-to-box variance of bench.py is +-1.5 %, larger than most kernel-level changes.  GPU only; dev tool.
 
     python tools/step_ab.py base,product [rounds] [steps-per-round]      # env: arch=vit_b_16|vit_s_16|..., robust=1
+A name may carry host-side switches: `product+bf16gelu` runs the product library with the bf16 gelu' stream of rounds 1 - 3
+(encoder.GELU_STREAM_U8 = False).
 """
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +29,15 @@ gen = torch.Generator(device=dev).manual_seed(1234)
 x = torch.randn(batch, 3, kw["image_size"], kw["image_size"], generator=gen, device=dev).to(torch.bfloat16)
 y = torch.randint(0, 1000, (batch,), generator=gen, device=dev)
 
+from noise_robust_vit_amd import encoder as _enc
+
+
+def select(name):
+    lib, *flags = name.split("+")
+    _devlib.use_library(lib)
+    _enc.GELU_STREAM_U8 = "bf16gelu" not in flags
+
+
 def run(n):
     e = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
     for i in range(n):
@@ -35,11 +46,11 @@ def run(n):
     return [e[i].elapsed_time(e[i + 1]) for i in range(n)]
 
 for l in libs:
-    _devlib.use_library(l); run(3)
+    select(l); run(3)
 res = {l: [] for l in libs}
 for _ in range(rounds):
     for l in libs:
-        _devlib.use_library(l)
+        select(l)
         run(1)
         res[l] += run(steps)
 ref = statistics.median(res[libs[0]])
@@ -51,7 +62,7 @@ for l in libs:
 # per-kernel-class device time inside the step (HIP events around every C-ABI launch), per library
 from noise_robust_vit_amd import kernels as K
 for l in libs:
-    _devlib.use_library(l)
+    select(l)
     trainer.forward_backward(x, y)
     with K.LaunchProfile() as prof:
         for _ in range(3):
