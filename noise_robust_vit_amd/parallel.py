@@ -18,8 +18,8 @@ encoder path produces gradients:
     keep every link streaming;
   * `finish_step()` waits for all collectives (compute stream waits on the RCCL stream) before clip + AdamW;
   * knobs sized for xGMI (7 point-to-point links x ~153 GB/s per GPU, ring collectives per-link bound): `grad_dtype="bf16"`
-    halves the bytes on the links (ViT-B/16: 173 instead of 346 MB per step; each bucket is cast into a bf16 staging slab by
-    nrv_cast_f32_bf16, reduced, and converted back into the fp32 buffer the optimizer reads), `tail_mib` caps the LAST
+    halves the bytes on the links (ViT-B/16: 173 instead of 346 MB per step; each bucket's range of ONE persistent bf16 image of the flat buffer is
+    written by nrv_cast_f32_bf16 and reduced in place; on the HIP device the optimizer reads that image directly), `tail_mib` caps the LAST
     bucket in backward order (patch embedding / first layers: the only one with no backward work left to hide behind),
     `make_process_group(..., max_ctas=...)` bounds the CUs RCCL's kernels may occupy next to GEMMs that hold every CU.
 
