@@ -370,6 +370,10 @@ def attn_half_fwd(x: Tensor, B: int, N: int, meta: BlockMeta, ln_w, ln_b, wqkv, 
         y = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=bo, aux=x)
     else:
         y = K.gemm_nt(o, wo_b, out_dtype=torch.float32, epilogue=EPI_BIAS if bo is not None else EPI_NONE, bias=bo)
+        if drop is not None:             # stand-alone module (learnable_memory_vit.py:61): dropout on the projection's output
+            scale, site = drop
+            keep = draw_keep(meta, site, y.shape, x.device)
+            K.mask_mul_f32(y, keep, scale, out=y)
     return y, (x, xn, mean, rstd, qkv, o, aux, keep)
 
 
@@ -432,7 +436,7 @@ def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residua
     u = torch.empty(T, w1.shape[0], dtype=torch.uint8 if q8 else torch.bfloat16, device=x.device) if save else None
     h = K.gemm_nt(xn, w1_b, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU_Q8 if q8 else EPI_BIAS_GELU, bias=b1, aux_out=u)
     keep2 = None
-    if residual and drop is not None:
+    if drop is not None:
         # Dropout behind the GELU (vit.py:100) and behind the second Linear (vit.py:101).  The first mask is applied to the saved
         # activation AND to the gelu' stream, so the backward (dW2 = dY^T h, dU = dY W2 o gelu') needs no mask of its own.
         scale, site = drop
@@ -440,9 +444,10 @@ def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residua
         K.mask_mul(h, keep1, scale, out=h)
         if u is not None:
             K.mask_mul(u, keep1, scale, out=u)
-        keep2 = draw_keep(meta, site + 1, x.shape, x.device)
         yb = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS if b2 is not None else EPI_NONE, bias=b2)
-        y = K.dropout_add(x, yb, keep2, scale, out=yb)
+        keep2 = draw_keep(meta, site + 1, yb.shape, x.device)
+        # with a residual the kept part of the branch is added to the stream; the stand-alone module (learnable_memory_vit.py:37-39) returns it
+        y = K.dropout_add(x, yb, keep2, scale, out=yb) if residual else K.mask_mul_f32(yb, keep2, scale, out=yb)
     elif residual:
         y = K.gemm_nt(h, w2_b, out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, bias=b2, aux=x)
     else:
@@ -563,16 +568,20 @@ class AttnHalfFn(torch.autograd.Function):
     def forward(ctx, x, meta: BlockMeta, ln_w, ln_b, wqkv, bqkv, wo, bo):
         x2, B, N, D = _as_stream(x)
         pa = float(meta.attn_dropout)
+        pd = float(meta.dropout)
         y, saved = attn_half_fwd(x2, B, N, meta, ln_w, ln_b, wqkv, bqkv, wo, bo, residual=False,
+                                 drop=(1.0 / (1.0 - pd), 0) if pd > 0.0 else None,
                                  adrop=(1.0 / (1.0 - pa), -2, pa) if pa > 0.0 else None)
         ctx.meta, ctx.params, ctx.saved_half, ctx.shape = meta, (ln_w, ln_b, wqkv, bqkv, wo, bo), saved, (B, N, D)
+        ctx.drop_scale = 1.0 / (1.0 - pd) if pd > 0.0 else 1.0
         return y.reshape(B, N, wo.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         B, N, D = ctx.shape
         d32 = dy.to(torch.float32).contiguous().reshape(B * N, -1)
-        dx32, _, g = attn_half_bwd(d32, None, ctx.saved_half, B, N, ctx.meta, *ctx.params, residual=False, want_bf16=False)
+        dx32, _, g = attn_half_bwd(d32, None, ctx.saved_half, B, N, ctx.meta, *ctx.params, residual=False, want_bf16=False,
+                                   drop_scale=ctx.drop_scale)
         return (dx32.reshape(B, N, D), None, *_mask_sink_grads(ctx.meta, g))
 
 
@@ -582,15 +591,17 @@ class MlpHalfFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2):
         x2, B, N, D = _as_stream(x)
-        y, saved = mlp_half_fwd(x2, meta, ln_w, ln_b, w1, b1, w2, b2, residual=False)
+        pd = float(meta.dropout)
+        y, saved = mlp_half_fwd(x2, meta, ln_w, ln_b, w1, b1, w2, b2, residual=False, drop=(1.0 / (1.0 - pd), 1) if pd > 0.0 else None)
         ctx.meta, ctx.params, ctx.saved_half, ctx.shape = meta, (ln_w, ln_b, w1, b1, w2, b2), saved, (B, N, D)
+        ctx.drop_scale = 1.0 / (1.0 - pd) if pd > 0.0 else 1.0
         return y.reshape(B, N, w2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         B, N, D = ctx.shape
         d32 = dy.to(torch.float32).contiguous().reshape(B * N, -1)
-        dx32, _, g = mlp_half_bwd(d32, None, ctx.saved_half, ctx.meta, *ctx.params, residual=False, want_bf16=False)
+        dx32, _, g = mlp_half_bwd(d32, None, ctx.saved_half, ctx.meta, *ctx.params, residual=False, want_bf16=False, drop_scale=ctx.drop_scale)
         return (dx32.reshape(B, N, D), None, *_mask_sink_grads(ctx.meta, g))
 
 

@@ -31,11 +31,6 @@ class _FusedRowsFn(torch.autograd.Function):
         return None, g[:ctx.rows], g[ctx.rows:]
 
 
-def _no_dropout(p: float) -> None:
-    if p != 0.0:
-        raise NotImplementedError(f"dropout={p}: the fused HIP path implements p=0 only")
-
-
 class PatchUnfoldFlat(PatchUnfold):
     """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (learnable_memory_vit.py:120)."""
 
@@ -57,7 +52,8 @@ class FeedForward(nn.Module):
         return [n[0].weight, n[0].bias, n[1].weight, n[1].bias, n[4].weight, n[4].bias]
 
     def forward(self, x):
-        _no_dropout(self.p if self.training else 0.0)
+        # stand-alone use (inside a Transformer the stack runs): dropout behind the GELU and behind the second Linear (learnable_memory_vit.py:37,39)
+        self._meta.dropout = self.p if self.training else 0.0
         return MlpHalfFn.apply(x, self._meta, *self.layer_params())
 
 
@@ -126,7 +122,8 @@ class Attention(nn.Module):
     def forward(self, x, attn_mask=None, memories=None):
         if attn_mask is not None or memories is not None:
             raise NotImplementedError("attention masks / memory tokens are outside the encoder hot path")
-        _no_dropout(self.p if self.training else 0.0)
+        # stand-alone use: dropout on the attention weights (learnable_memory_vit.py:83; composed on the materialised matrix) and behind to_out (:61)
+        self._meta.dropout = self._meta.attn_dropout = self.p if self.training else 0.0
         return AttnHalfFn.apply(x, self._meta, *self.layer_params())
 
 

@@ -908,6 +908,42 @@ def test_lucid_vit_dropout_against_oracle_with_injected_masks(dev):
     check_grads(model, {k: v.grad for k, v in leaves.items()}, tol=2.0e-2)
 
 
+def test_lucid_standalone_attention_and_feedforward_dropout_against_oracle(dev):
+    """`Attention(dropout=p)` / `FeedForward(dropout=p)` used on their own (learnable_memory_vit.py:30-86): the dropout on the attention
+    weights and behind to_out, behind the GELU and behind the second Linear, with the oracle's masks; eval mode ignores p."""
+    from noise_robust_vit_amd.lucid_vit import Attention, FeedForward
+    from oracle import mae_oracle as MO
+    from oracle.simple_vit_oracle import _Q
+    torch.manual_seed(3)
+    p = 0.2
+    keep = _keep_family(41, p)
+    x = torch.randn(3, 50, 128)
+    for kind in ("attention", "feed_forward"):
+        mod = Attention(128, heads=2, dim_head=64, dropout=p) if kind == "attention" else FeedForward(128, 256, dropout=p)
+        sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+        mod = mod.to(dev).train()
+        mod._meta.mask_source = keep
+        xin = x.to(dev).requires_grad_(True)
+        y = mod(xin)
+        y.square().mean().backward()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        f = (lambda t, d: MO.lucid_attention(t, leaves, "", 2, 64, _Q(False), d, 0)) if kind == "attention" else \
+            (lambda t, d: MO.lucid_feed_forward(t, leaves, "", _Q(False), d, 0))
+        ref = f(xr, (p, keep))
+        ref.square().mean().backward()
+        with torch.no_grad():
+            plain = f(x, None)
+        e = relmax(y, ref)
+        print(f"stand-alone {kind} with dropout {p}: vs fp32 oracle (same masks) {e:.3e}; the masks move the output by {relmax(ref, plain):.2e}")
+        assert e < 1.2e-2 and relmax(ref, plain) > 10 * e
+        assert ((xin.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item() < 2e-2
+        check_grads(mod, {k: v.grad for k, v in leaves.items()}, tol=2.0e-2)
+        mod.eval()
+        with torch.no_grad():
+            assert relmax(mod(x.to(dev)), plain) < 1.2e-2
+
+
 def test_mae_gradients_through_the_reducer_sink_match_autograd(dev):
     """With a GradReducer attached (every training step: train.Trainer builds one even on a single GPU) both MAE transformers
     write their weight gradients into the flat buffer directly -- the fused [to_q; to_kv] projection as one TN GEMM per
