@@ -94,7 +94,10 @@ int nrv_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const flo
  *   aux_out: optional bf16 [M,N] (ldc_aux) receiving gelu'(pre-activation) for NRV_EPI_BIAS_GELU: the backward's
  *        NRV_EPI_DGELU epilogue is then one multiply, no second erf/exp evaluation.
  *        The _Q8 pair keeps the same stream in one byte per element (gelu_erf' lies in [-0.129, 1.129]; step 1/202, i.e. an
- *        absolute error <= 0.0025 -- what bf16 leaves on values in [0.5, 1)): ld_aux_out % 16 == 0, aux_dtype = NRV_U8 on the way back.
+ *        absolute error <= 0.0025 -- what bf16 leaves on values in [0.5, 1)): aux_dtype = NRV_U8 on the way back.  The byte stream is
+ *        private to the pair and stored in ROW PAIRS, byte (m, n) at (m >> 1) * 2 ld + (n >> 6) * 128 + (m & 1) * 64 + (n & 63)
+ *        (the 2 x 64 bytes a wave touches are one 128-byte line): N % 64 == 0, ld % 16 == 0, ld >= N, and the buffer holds M rounded up
+ *        to an even number of rows of ld bytes.
  *   Output row remap (class-token slot, vit.py:341-342): if out_group > 0 the result row m is
  *   stored at row (m / out_group) * out_group_stride + (m % out_group) + out_row_offset of C
  *   (and of aux, when aux_row_mod == 0).  The remap and aux_row_mod ride on NRV_EPI_BIAS_RESIDUAL (the patch

@@ -199,15 +199,24 @@ __device__ __forceinline__ void epilogue_lin(f32x4_t (&acc)[MI][4], float* stg /
     const unsigned c_vo = col_ok ? (unsigned)(rrow * c_rs + rcol * CW * ES) : NRV_OOB;
     int a_rs = HAS_AUX ? (int)e.ld_aux * AS : 0;
     asm volatile("" : "+s"(a_rs));
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(HAS_AUX ? static_cast<const char*>(e.aux) + ((long long)row_base * e.ld_aux + col_base) * AS : nullptr,
-                                                HAS_AUX ? ((unsigned long long)(rows_here - 1) * e.ld_aux + cols_here) * AS : 0ull);
-    const unsigned a_vo = (HAS_AUX && col_ok) ? (unsigned)(rrow * a_rs + rcol * CW * AS) : NRV_OOB;
+    // The 8-bit stream is stored in ROW PAIRS: byte (m, n) at (m >> 1) * 2 ld + (n >> 6) * 128 + (m & 1) * 64 + (n & 63) (include/nrv.h), so that the 64 columns
+    // x 2 rows a wave touches are ONE 128-byte line.  Row-major, a wave's 64 bytes per row are half a line, and what a CU can take in is a number of LINES
+    // (~1 per 6.4 cycles: the K loop's own bound): the half lines cost the dU launch as much as the bf16 stream's full ones
+    // (profiles/r04_gelu_stream_8bit_and_epilogue_bounds.txt).  row_base and every pass's first row are even, N % 64 == 0 (host).
+    constexpr bool QA = Q8 && epi_dgelu(EPI), QU = Q8 && epi_gelu(EPI);
+    const int last_row = rows_here - 1;
+    const unsigned long long q8_records = (unsigned long long)(last_row >> 1) * 2ull * (unsigned long long)(QA ? e.ld_aux : e.ld_aux_out) + (last_row & 1) * 64 + 64;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(HAS_AUX ? static_cast<const char*>(e.aux) + (QA ? (long long)row_base * e.ld_aux + (col_base >> 6) * 128
+                                                                                                   : ((long long)row_base * e.ld_aux + col_base) * AS) : nullptr,
+                                                HAS_AUX ? (QA ? q8_records : ((unsigned long long)(rows_here - 1) * e.ld_aux + cols_here) * AS) : 0ull);
+    const unsigned a_vo = (HAS_AUX && col_ok) ? (QA ? (unsigned)((rrow >> 1) * 2 * a_rs + (rrow & 1) * 64 + rcol * 8) : (unsigned)(rrow * a_rs + rcol * CW * AS)) : NRV_OOB;
     const bool want_u = epi_gelu(EPI) && e.aux_out != nullptr;
     int u_rs = want_u ? (int)e.ld_aux_out * US : 0;
     asm volatile("" : "+s"(u_rs));
-    const __amdgpu_buffer_rsrc_t ru = make_rsrc(want_u ? static_cast<char*>(e.aux_out) + ((long long)row_base * e.ld_aux_out + col_base) * US : nullptr,
-                                                want_u ? ((unsigned long long)(rows_here - 1) * e.ld_aux_out + cols_here) * US : 0ull);
-    const unsigned u_vo = (want_u && col_ok) ? (unsigned)(rrow * u_rs + rcol * CW * US) : NRV_OOB;
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(want_u ? static_cast<char*>(e.aux_out) + (QU ? (long long)row_base * e.ld_aux_out + (col_base >> 6) * 128
+                                                                                                  : ((long long)row_base * e.ld_aux_out + col_base) * US) : nullptr,
+                                                want_u ? (QU ? q8_records : ((unsigned long long)(rows_here - 1) * e.ld_aux_out + cols_here) * US) : 0ull);
+    const unsigned u_vo = (want_u && col_ok) ? (QU ? (unsigned)((rrow >> 1) * 2 * u_rs + (rrow & 1) * 64 + rcol * 8) : (unsigned)(rrow * u_rs + rcol * CW * US)) : NRV_OOB;
 
     f32x4_t bias4[V];
 #pragma unroll
@@ -1796,6 +1805,7 @@ extern "C" int nrv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     // the epilogue addresses a wave's block (<= 160 rows) with 32-bit byte offsets
     if (ldc * 4 * 320 >= 0x7fffffffll || ld_aux * 4 * 320 >= 0x7fffffffll || ld_aux_out * 2 * 320 >= 0x7fffffffll) return NRV_ERR_SHAPE;
     if (epi_q8(epilogue_id) && c_dtype != NRV_BF16) return NRV_ERR_DTYPE;                    // the byte stream goes with bf16 outputs
+    if (epi_q8(epilogue_id) && (N & 63)) return NRV_ERR_SHAPE;                                // ... in 64-column blocks of row pairs
     const bool need_aux = epilogue_id == NRV_EPI_BIAS_RESIDUAL || epi_dgelu(epilogue_id);
     if (need_aux) {
         if (!aux) return NRV_ERR_EPILOGUE;

@@ -432,8 +432,8 @@ def mlp_half_fwd(x: Tensor, meta: BlockMeta, ln_w, ln_b, w1, b1, w2, b2, residua
     T = x.shape[0]
     # gelu'(pre-activation) for the backward: one byte per element (include/nrv.h NRV_EPI_BIAS_GELU_Q8) unless a dropout mask is
     # going to be multiplied into it (a scaled value leaves the byte code's range)
-    q8 = GELU_STREAM_U8 and drop is None and w1.shape[0] % 16 == 0
-    u = torch.empty(T, w1.shape[0], dtype=torch.uint8 if q8 else torch.bfloat16, device=x.device) if save else None
+    q8 = GELU_STREAM_U8 and drop is None and w1.shape[0] % 64 == 0
+    u = torch.empty((T + 1) // 2 * 2 if q8 else T, w1.shape[0], dtype=torch.uint8 if q8 else torch.bfloat16, device=x.device) if save else None
     h = K.gemm_nt(xn, w1_b, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU_Q8 if q8 else EPI_BIAS_GELU, bias=b1, aux_out=u)
     keep2 = None
     if drop is not None:

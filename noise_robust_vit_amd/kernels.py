@@ -184,6 +184,8 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
         arows, acols, ld_aux = _rows2d(aux, "aux")
         # the epilogue reads aux through raw pointers: row m % aux_row_mod, or the (remapped) output row
         need = aux_row_mod if aux_row_mod else (M if not out_group else (M - 1) // out_group * out_group_stride + (M - 1) % out_group + out_row_offset + 1)
+        if epilogue == EPI_DGELU_Q8:
+            need = (need + 1) // 2 * 2          # the byte stream is stored in row pairs (include/nrv.h)
         if arows < need or acols < N:
             raise NrvError(f"gemm_nt: aux is [{arows}, {acols}] but the epilogue reads rows < {need}, columns < {N}")
     if out_group:
@@ -196,8 +198,8 @@ def gemm_nt(A: Tensor, B: Tensor, *, out_dtype: torch.dtype = torch.bfloat16, ep
     if aux_out is not None:
         if epilogue == EPI_BIAS_GELU_Q8:
             _dev(aux_out, "aux_out")
-            if aux_out.dtype != torch.uint8:
-                raise NrvError("gemm_nt: EPI_BIAS_GELU_Q8 writes the gelu' stream as uint8")
+            if aux_out.dtype != torch.uint8 or aux_out.shape[0] < (M + 1) // 2 * 2 or N % 64:
+                raise NrvError("gemm_nt: EPI_BIAS_GELU_Q8 writes the gelu' stream as uint8 in row pairs: M rounded up to even rows, N % 64 == 0")
         else:
             _bf16(aux_out, "aux_out")
         _, _, ld_ao = _rows2d(aux_out, "aux_out")

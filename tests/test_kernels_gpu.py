@@ -235,25 +235,31 @@ def test_gemm_nt_many_tiles(dev, M, N, K):
         assert out.reshape(M // G, G + 1, N)[:, 0].abs().max() == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(50432, 3072, 768), (1000, 264, 136), (321, 72, 64), (2000, 1536, 384), (7, 8, 8)])
+@pytest.mark.parametrize("M,N,K", [(50432, 3072, 768), (1000, 320, 136), (321, 64, 64), (2001, 1536, 384), (7, 64, 8)])
 def test_gemm_nt_gelu_stream_8bit(dev, M, N, K):
     """NRV_EPI_BIAS_GELU_Q8 / NRV_EPI_DGELU_Q8 (include/nrv.h): the same GELU output as the bf16-stream epilogue, bit for bit; the
-    byte q stands for gelu'(u) = (q - 26) / 202 to half a step (0.0025) + the kernel's erf approximation; the backward epilogue
-    multiplies by exactly the decoded value; nothing is written outside the stream's [M, N] block."""
+    byte q stands for gelu'(u) = (q - 26) / 202 to half a step (0.0025) + the kernel's erf approximation, stored in row pairs (byte (m, n) at
+    (m >> 1) 2 ld + (n >> 6) 128 + (m & 1) 64 + (n & 63)); the backward epilogue multiplies by exactly the decoded value; nothing is written
+    outside the stream's block (odd M: the second row of the last pair stays untouched)."""
     k = _k()
     from noise_robust_vit_amd._lib import EPI_BIAS_GELU, EPI_BIAS_GELU_Q8, EPI_DGELU_Q8
     A = rnd((M, K), dev, 26, 0.5)
     B = rnd((N, K), dev, 27, 0.3)
     bias = rnd((N,), dev, 28, 1.0, torch.float32)
     h16 = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, bias=bias)
-    PADR, ld = 3, (N + 31) // 16 * 16
-    qbig = torch.full((M + 2 * PADR, ld), 255, dtype=torch.uint8, device=dev)
-    q = qbig[PADR:PADR + M, :N]
-    h = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU_Q8, bias=bias, aux_out=q)
+    PADR, ld, ME = 4, (N + 31) // 16 * 16, (M + 1) // 2 * 2
+    qbig = torch.full((ME + 2 * PADR, ld), 255, dtype=torch.uint8, device=dev)
+    qbuf = qbig[PADR:PADR + ME, :N]                            # what the kernels are given: ME rows of ld bytes, the first N of each are the stream's
+    h = k.gemm_nt(A, B, out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU_Q8, bias=bias, aux_out=qbuf)
     assert torch.equal(h, h16)
+    pairs = qbig[PADR:PADR + ME].reshape(ME // 2, 2 * ld)      # a row pair = 2 ld bytes: N / 64 lines of [row 2p: 64 bytes][row 2p + 1: 64 bytes], then padding
+    q = pairs[:, :2 * N].reshape(ME // 2, N // 64, 2, 64).permute(0, 2, 1, 3).reshape(ME, N)[:M]
     guard = qbig.clone()
-    guard[PADR:PADR + M, :N] = 255
+    gp = guard[PADR:PADR + ME].reshape(ME // 2, 2 * ld)
+    gp[:, :2 * N] = 255                                          # the stream's own bytes ...
     assert (guard == 255).all(), "the 8-bit gelu' stream was written outside its block"
+    if M % 2:                                                    # ... of which the odd last pair's second row was not written either
+        assert (pairs[-1, :2 * N].reshape(N // 64, 2, 64)[:, 1] == 255).all()
     pre = (A.float() @ B.float().t() + bias).requires_grad_(True)
     torch.nn.functional.gelu(pre).sum().backward()
     g = (q.float() - 26.0) / 202.0
@@ -263,11 +269,11 @@ def test_gemm_nt_gelu_stream_8bit(dev, M, N, K):
     del pre
     dY = rnd((M, 2 * K), dev, 29, 0.5)
     W = rnd((N, 2 * K), dev, 30, 0.2)
-    c = k.gemm_nt(dY, W, out_dtype=torch.bfloat16, epilogue=EPI_DGELU_Q8, aux=q)
+    c = k.gemm_nt(dY, W, out_dtype=torch.bfloat16, epilogue=EPI_DGELU_Q8, aux=qbuf)
     ref = (dY.float() @ W.float().t()) * g
     assert ((c.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-5 * math.sqrt(2 * K) * ref.abs().max()).all()
     with pytest.raises(Exception):
-        k.gemm_nt(dY, W, out_dtype=torch.float32, epilogue=EPI_DGELU_Q8, aux=q)       # bf16 outputs only
+        k.gemm_nt(dY, W, out_dtype=torch.float32, epilogue=EPI_DGELU_Q8, aux=qbuf)    # bf16 outputs only
     with pytest.raises(Exception):
         k.gemm_nt(dY, W, out_dtype=torch.bfloat16, epilogue=EPI_DGELU_Q8, aux=h)      # a bf16 stream with the byte epilogue
 
